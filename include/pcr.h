@@ -1,0 +1,192 @@
+/*
+ * pcr.h -- C ABI of libpcr.so, the MI355X (gfx950) device library for the ICP
+ * fine-registration hot path of fufesou/PointCloudRegistration.
+ *
+ * This is the drop-in boundary: every entry point below is what a binding on the
+ * reference side would call in place of the reference function cited next to it
+ * (paths relative to /root/reference; see INTEGRATION.md for the C++ stubs).
+ *
+ * Conventions
+ *   - return 0 (PCR_OK) on success, a negative pcr_status otherwise; never throws,
+ *     no C++/STL/torch types cross the boundary; handles are opaque.
+ *   - pointers are HOST pointers unless the parameter name ends in _d (device).
+ *   - points are AoS double[3n] (x,y,z), exactly CPointCloud::getPosPointer()
+ *     (PointCloudRegistration/PointCloud.h:19); indices are uint32_t; R is 3x3
+ *     COLUMN-major (Eigen::Matrix3d::data()), T is 3 doubles.
+ *   - all arithmetic that decides an index is IEEE fp64 without FMA contraction, in
+ *     the reference's operation order (PointCloud.cpp:368-370, Common/KNNSearch.h:137-143).
+ *   - neighbour selection is the exact K nearest under the total order (d2, index):
+ *     identical to the reference whenever no two candidates are exactly equidistant
+ *     from the query; on exact ties the reference keeps the first one visited in
+ *     KD-tree order (Common/KNNSearch.h:75) and this library keeps the lowest index.
+ *   - a context is used by one host thread at a time; distinct contexts are independent.
+ *     Entry points without a _d suffix are synchronous; _d entry points enqueue on the
+ *     context's stream and return (call pcr_ctx_synchronize, or order later work on the
+ *     same stream).
+ */
+#ifndef PCR_H
+#define PCR_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PCR_OK = 0,
+    PCR_E_INVALID = -1,    /* bad argument (NULL, k == 0, k > n, dim != 3, ...)        */
+    PCR_E_HIP = -2,        /* a HIP runtime call failed; pcr_last_error() has the text */
+    PCR_E_NOMEM = -3,      /* device or host allocation failed                        */
+    PCR_E_UNSUPPORTED = -4,/* k above PCR_MAX_K, index kind not built, ...            */
+    PCR_E_EMPTY = -5,      /* no correspondence survived (reference divides by zero:  */
+                           /*   RegUtilityFunctions.cpp:71)                           */
+    PCR_E_NO_DEVICE = -6   /* no HIP device / wrong architecture                      */
+} pcr_status;
+
+#define PCR_NO_INDEX 0xFFFFFFFFu
+#define PCR_MAX_K 32u
+#define PCR_NUM_PARTIALS 17u
+
+typedef struct pcr_ctx pcr_ctx;
+typedef struct pcr_cloud pcr_cloud;
+typedef struct pcr_index pcr_index;
+
+const char *pcr_strerror(int status);
+/* text of the last failure on this thread (HIP error string, argument that was rejected) */
+const char *pcr_last_error(void);
+/* library version string; also names the target ISA it was compiled for */
+const char *pcr_version(void);
+
+/* ---- context -----------------------------------------------------------------------
+ * No reference counterpart (the reference is single-threaded CPU code).  One context =
+ * one device + one HIP stream + reusable scratch.  stream may be NULL (the context then
+ * creates its own) or an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
+int pcr_ctx_create(int device, void *hip_stream, pcr_ctx **out);
+int pcr_ctx_destroy(pcr_ctx *ctx);
+int pcr_ctx_synchronize(pcr_ctx *ctx);
+
+/* ---- clouds ------------------------------------------------------------------------
+ * Replaces the borrowed `const double*` of hiveCommon::CKNNSearch::initKNNSearch
+ * (Common/KNNSearch.cpp:17-26) and hiveSearch::CBaseSearch::setInputData
+ * (PointCloudRegistration/BaseSearch.cpp:27-33).  pcr_cloud_upload COPIES (the caller keeps
+ * its memory); pcr_cloud_wrap_d borrows device memory that must outlive the cloud. */
+int pcr_cloud_upload(pcr_ctx *ctx, const double *xyz, uint32_t n, pcr_cloud **out);
+int pcr_cloud_wrap_d(pcr_ctx *ctx, const double *xyz_d, uint32_t n, pcr_cloud **out);
+int pcr_cloud_free(pcr_cloud *cloud);
+uint32_t pcr_cloud_size(const pcr_cloud *cloud);
+/* axis-aligned bounds lo[3], hi[3] -- hiveCommon::CKNNSearch::__computeBoundingBox,
+ * Common/KNNSearch.cpp:96-116 */
+int pcr_cloud_bounds(const pcr_cloud *cloud, double lo[3], double hi[3]);
+
+/* ---- index build -------------------------------------------------------------------
+ * Replaces hiveCommon::CKNNSearch::initKNNSearch -> __buildSearchIndex
+ * (Common/KNNSearch.cpp:17,79-92) and hiveSearch::CKNNSearch::_buildAccelerationStructureV
+ * (PointCloudRegistration/NewKNNSearch.cpp:22-28).  The structure is a uniform grid built on
+ * the device (cell histogram -> exclusive scan -> scatter into cell order), or nothing at
+ * all for the tiled brute-force kernel used on small clouds. */
+typedef enum { PCR_INDEX_AUTO = 0, PCR_INDEX_GRID = 1, PCR_INDEX_BRUTE = 2 } pcr_index_kind;
+typedef struct {
+    int kind;                 /* pcr_index_kind; AUTO = BRUTE for n <= brute_max_points    */
+    double target_occupancy;  /* mean points per OCCUPIED cell the build aims at; <=0: 2.0 */
+    double cell_size;         /* > 0 fixes the cell edge and skips the occupancy search   */
+    uint64_t max_cells;       /* cap on grid cells (dense cell table); 0: 2^30            */
+    uint32_t brute_max_points;/* AUTO threshold; 0: 2048                                  */
+} pcr_index_params;
+typedef struct {
+    int kind;
+    uint32_t n, dims[3];
+    uint64_t cells, occupied_cells;
+    double cell_size, mean_occupancy;
+    uint32_t max_occupancy;
+    uint64_t device_bytes;
+} pcr_index_info;
+int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params *params /*nullable*/,
+                    pcr_index **out);
+int pcr_index_free(pcr_index *index);
+int pcr_index_get_info(const pcr_index *index, pcr_index_info *info);
+
+/* ---- exact K-NN --------------------------------------------------------------------
+ * Replaces hiveCommon::CKNNSearch::executeKNN (Common/KNNSearch.cpp:33-43,65-75; ascending
+ * distance = PCR_ORDER_ASCENDING) and hiveSearch::CBaseSearch::executeSearch ->
+ * CKNNSearch::_executeSearchV (BaseSearch.cpp:37-60, NewKNNSearch.cpp:32-68; row-major
+ * [nq x k], farthest first = PCR_ORDER_DESCENDING).  out_d2 (nullable) receives the squared
+ * distances in the same order.  max_d2 bounds the search: neighbours with d2 >= max_d2 are
+ * not reported (their slots hold PCR_NO_INDEX / +inf); pass a negative value or +inf for an
+ * unbounded search (the reference behaviour). */
+typedef enum { PCR_ORDER_ASCENDING = 0, PCR_ORDER_DESCENDING = 1 } pcr_order;
+int pcr_knn(pcr_ctx *ctx, const pcr_index *index, const double *q, uint32_t nq, uint32_t k, int order,
+            double max_d2, uint32_t *out_idx, double *out_d2 /*nullable*/);
+int pcr_knn_d(pcr_ctx *ctx, const pcr_index *index, const double *q_d, uint32_t nq, uint32_t k, int order,
+              double max_d2, uint32_t *out_idx_d, double *out_d2_d /*nullable*/);
+
+/* ---- CUniqueData::setPointCloud (PointCloudRegistration/UniqueData.cpp:25-53) ----------
+ * Mean squared distance to the 4 nearest neighbours (self included) over the ~20 evenly
+ * strided points of the cloud the index was built on; reuses the index instead of building a
+ * throw-away tree. */
+int pcr_unique_sq_dist(pcr_ctx *ctx, const pcr_index *index, double *out);
+
+/* ---- one ICRP iteration ------------------------------------------------------------
+ * Replaces, fused into device work:
+ *   CCorrespondenceEstimationClosestPoints::_determineCorrespondencesV
+ *        (FineRegistrationClosestPoints/CorrespondenceEstimationClosestPoints.cpp:54-117)
+ *   CPointCloud::transform of the whole source        (PointCloud.cpp:358-371; :73-74)
+ *   the per-iteration source KD-tree rebuild           (:77-78) -- replaced by ONE source index
+ *        built in the source frame and searched with transformed candidates
+ *   CCorrespondenceRejectionClosestPoints (pass-through, CorrespondenceRejectionClosestPoints.cpp:18-22)
+ *   compute3DCentroid x2 + __deMean + __buildPointPairMatrix + H = A*B^T
+ *        (RegUtilityFunctions.cpp:44-72, TransformationEstimationSVD2.cpp:33-103)
+ *   CDefaultConvergenceCriteria::__calculateMSE         (DefaultConvergenceCriterial.cpp:46-65)
+ *
+ * For each sample i (sample_idx NULL = every source point, in index order):
+ *   p = R*s + T;  j = K-th nearest target point of p;  q = tgt[j];
+ *   r = nearest transformed source point of q;  p' = R*src[r] + T;
+ *   keep = |p-q|^2 < thr_fwd_sq  &&  |p-p'|^2 < thr_rev_sq            (strict <, :97-98)
+ * and over the kept samples the 17 partial sums
+ *   partials[0]      n
+ *   partials[1..3]   sum (p - pivot_p)
+ *   partials[4..6]   sum (q - pivot_q)
+ *   partials[7..15]  sum (p - pivot_p)(q - pivot_q)^T   row-major, row = p component
+ *   partials[16]     sum |p-q|^2
+ * with pivot_p = R*c_src + T and pivot_q = c_tgt, c_* = centre of the cloud's bounds
+ * (pcr_icp_pivots returns them).  The pivots only condition the sums; pcr_solve_rigid removes them.
+ *
+ * flags: PCR_STEP_EXACT_INDICES makes out_fwd/out_rev the reference's values for EVERY sample;
+ * without it a sample whose forward distance already fails the gate may report PCR_NO_INDEX in
+ * out_fwd/out_rev (keep and partials are identical either way).
+ * Outputs out_fwd[m], out_rev[m], out_keep[m] are nullable. */
+#define PCR_STEP_EXACT_INDICES 1u
+int pcr_icp_step(pcr_ctx *ctx, const pcr_index *src_index, const pcr_index *tgt_index,
+                 const uint32_t *sample_idx /*nullable*/, uint32_t m, const double R[9], const double T[3],
+                 uint32_t k, double thr_fwd_sq, double thr_rev_sq, uint32_t flags, double partials[17],
+                 uint32_t *out_fwd, uint32_t *out_rev, uint8_t *out_keep);
+/* device-resident variant for the multi-GPU loop: sample_idx_d [m] (nullable) on the device,
+ * partials_d [17] on the device (ready for an RCCL all-reduce on the same stream). */
+int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src_index, const pcr_index *tgt_index,
+                   const uint32_t *sample_idx_d /*nullable*/, uint32_t sample_begin, uint32_t m,
+                   const double R[9], const double T[3], uint32_t k, double thr_fwd_sq, double thr_rev_sq,
+                   uint32_t flags, double *partials_d, uint32_t *out_fwd_d, uint32_t *out_rev_d,
+                   uint8_t *out_keep_d);
+int pcr_icp_pivots(const pcr_index *src_index, const pcr_index *tgt_index, const double R[9],
+                   const double T[3], double pivot_p[3], double pivot_q[3]);
+
+/* ---- host: CTransformationEstimationSVD2::__computeRelativeRotationAndTranslation
+ *      (TransformationEstimationSVD2.cpp:98-117) + accumulateTransformation
+ *      (BaseTransformationEstimation.h:28-32), fed by the 17 partials instead of pair lists.
+ * R,T in/out = accumulated transform; Rc,Tc (nullable) = this iteration's increment;
+ * mse (nullable) = partials[16]/n.  PCR_E_EMPTY if n == 0. */
+int pcr_solve_rigid(const double partials[17], const double pivot_p[3], const double pivot_q[3],
+                    double R[9], double T[3], double Rc[9], double Tc[3], double *mse);
+
+/* ---- CRejectionCentroidDist::_rejectInvalidPairsV (RejectionCentroidDist.cpp:23-153) ----
+ * pair_p = TRANSFORMED source points, queried against the UNTRANSFORMED source index
+ * (reference quirk, :52,:75); pair_q = target points.  out_keep[P]; out_d[P] (nullable) the
+ * per-pair statistic; out_stat[2] (nullable) = {mean, sigma}.  msn = MSN (25), msd = MSD (8.0,
+ * compared with a squared distance as the reference does), cdf = CDF. */
+int pcr_reject_centroid_dist(pcr_ctx *ctx, const pcr_index *src_index, const pcr_index *tgt_index,
+                             const double *pair_p, const double *pair_q, uint32_t P, uint32_t msn, double msd,
+                             double cdf, uint8_t *out_keep, double *out_d, double *out_stat);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCR_H */

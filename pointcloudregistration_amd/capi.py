@@ -1,0 +1,288 @@
+"""ctypes binding of libpcr.so (include/pcr.h) -- the only way Python reaches the device code.
+
+There is NO CPU fallback: if the shared library is missing or no gfx950 device is visible the
+calls raise.  torch is imported first on purpose: libpcr.so's DT_NEEDED `libamdhip64.so.7` then
+resolves to the HIP runtime torch already loaded, so device pointers and streams are shared
+between torch tensors and this library (one runtime per process).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch  # noqa: F401  (must precede loading libpcr.so, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpcr.so")
+
+NO_INDEX = 0xFFFFFFFF
+MAX_K = 32
+ORDER_ASCENDING, ORDER_DESCENDING = 0, 1
+INDEX_AUTO, INDEX_GRID, INDEX_BRUTE = 0, 1, 2
+STEP_EXACT_INDICES = 1
+
+_dp = C.POINTER(C.c_double)
+_up = C.POINTER(C.c_uint32)
+_bp = C.POINTER(C.c_uint8)
+_vp = C.c_void_p
+
+
+class PcrError(RuntimeError):
+    def __init__(self, status, what):
+        self.status = status
+        super().__init__(what)
+
+
+class IndexParams(C.Structure):
+    _fields_ = [("kind", C.c_int), ("target_occupancy", C.c_double), ("cell_size", C.c_double),
+                ("max_cells", C.c_uint64), ("brute_max_points", C.c_uint32)]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("kind", C.c_int), ("n", C.c_uint32), ("dims", C.c_uint32 * 3), ("cells", C.c_uint64),
+                ("occupied_cells", C.c_uint64), ("cell_size", C.c_double), ("mean_occupancy", C.c_double),
+                ("max_occupancy", C.c_uint32), ("device_bytes", C.c_uint64)]
+
+
+# every symbol include/pcr.h declares: (restype, argtypes)
+SYMBOLS = {
+    "pcr_strerror": (C.c_char_p, [C.c_int]),
+    "pcr_last_error": (C.c_char_p, []),
+    "pcr_version": (C.c_char_p, []),
+    "pcr_ctx_create": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
+    "pcr_ctx_destroy": (C.c_int, [_vp]),
+    "pcr_ctx_synchronize": (C.c_int, [_vp]),
+    "pcr_cloud_upload": (C.c_int, [_vp, _dp, C.c_uint32, C.POINTER(_vp)]),
+    "pcr_cloud_wrap_d": (C.c_int, [_vp, _vp, C.c_uint32, C.POINTER(_vp)]),
+    "pcr_cloud_free": (C.c_int, [_vp]),
+    "pcr_cloud_size": (C.c_uint32, [_vp]),
+    "pcr_cloud_bounds": (C.c_int, [_vp, _dp, _dp]),
+    "pcr_index_build": (C.c_int, [_vp, _vp, C.POINTER(IndexParams), C.POINTER(_vp)]),
+    "pcr_index_free": (C.c_int, [_vp]),
+    "pcr_index_get_info": (C.c_int, [_vp, C.POINTER(IndexInfo)]),
+    "pcr_knn": (C.c_int, [_vp, _vp, _dp, C.c_uint32, C.c_uint32, C.c_int, C.c_double, _up, _dp]),
+    "pcr_knn_d": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_int, C.c_double, _vp, _vp]),
+    "pcr_unique_sq_dist": (C.c_int, [_vp, _vp, _dp]),
+    "pcr_icp_step": (C.c_int, [_vp, _vp, _vp, _up, C.c_uint32, _dp, _dp, C.c_uint32, C.c_double, C.c_double,
+                               C.c_uint32, _dp, _up, _up, _bp]),
+    "pcr_icp_step_d": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _dp, _dp, C.c_uint32, C.c_double,
+                                 C.c_double, C.c_uint32, _vp, _vp, _vp, _vp]),
+    "pcr_icp_pivots": (C.c_int, [_vp, _vp, _dp, _dp, _dp, _dp]),
+    "pcr_solve_rigid": (C.c_int, [_dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "pcr_reject_centroid_dist": (C.c_int, [_vp, _vp, _vp, _dp, _dp, C.c_uint32, C.c_uint32, C.c_double, C.c_double,
+                                           _bp, _dp, _dp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libpcr.so (raises if it has not been built -- there is no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                              "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        L = lib()
+        raise PcrError(rc, f"{what}: {L.pcr_strerror(rc).decode()} -- {L.pcr_last_error().decode()}")
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _u(a):
+    return None if a is None else a.ctypes.data_as(_up)
+
+
+def _b(a):
+    return None if a is None else a.ctypes.data_as(_bp)
+
+
+def _f64(a, cols=3):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a.reshape(-1, cols) if cols else a
+
+
+def _rt(R, T):
+    return (np.ascontiguousarray(R, np.float64).reshape(9).copy(),
+            np.ascontiguousarray(T, np.float64).reshape(3).copy())
+
+
+class Context:
+    """pcr_ctx: one device + one stream.  stream: None (own stream) or a torch.cuda.Stream."""
+
+    def __init__(self, device=0, stream=None):
+        self.h = _vp()
+        sp = _vp(stream.cuda_stream) if stream is not None else None
+        _check(lib().pcr_ctx_create(device, sp, C.byref(self.h)), "pcr_ctx_create")
+        self.device = device
+
+    def synchronize(self):
+        _check(lib().pcr_ctx_synchronize(self.h), "pcr_ctx_synchronize")
+
+    def close(self):
+        if self.h:
+            lib().pcr_ctx_destroy(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Cloud:
+    """pcr_cloud.  `xyz` is a numpy (n,3) array (copied to the device) or a CUDA torch tensor of
+    float64 (n,3) (borrowed: kept alive by this object)."""
+
+    def __init__(self, ctx, xyz):
+        self.ctx = ctx
+        self.h = _vp()
+        if isinstance(xyz, torch.Tensor):
+            assert xyz.is_cuda and xyz.dtype == torch.float64 and xyz.is_contiguous()
+            self._keep = xyz
+            self.n = xyz.numel() // 3
+            _check(lib().pcr_cloud_wrap_d(ctx.h, _vp(xyz.data_ptr()), self.n, C.byref(self.h)), "pcr_cloud_wrap_d")
+        else:
+            a = _f64(xyz)
+            self.n = len(a)
+            _check(lib().pcr_cloud_upload(ctx.h, _d(a), self.n, C.byref(self.h)), "pcr_cloud_upload")
+
+    def bounds(self):
+        lo, hi = np.empty(3), np.empty(3)
+        _check(lib().pcr_cloud_bounds(self.h, _d(lo), _d(hi)), "pcr_cloud_bounds")
+        return lo, hi
+
+    def close(self):
+        if self.h:
+            lib().pcr_cloud_free(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Index:
+    """pcr_index over a Cloud."""
+
+    def __init__(self, ctx, cloud, kind=INDEX_AUTO, target_occupancy=0.0, cell_size=0.0, max_cells=0,
+                 brute_max_points=0):
+        self.ctx, self.cloud = ctx, cloud
+        self.h = _vp()
+        prm = IndexParams(kind, target_occupancy, cell_size, max_cells, brute_max_points)
+        _check(lib().pcr_index_build(ctx.h, cloud.h, C.byref(prm), C.byref(self.h)), "pcr_index_build")
+        self.n = cloud.n
+
+    def info(self):
+        inf = IndexInfo()
+        _check(lib().pcr_index_get_info(self.h, C.byref(inf)), "pcr_index_get_info")
+        return {f: (list(getattr(inf, f)) if f == "dims" else getattr(inf, f)) for f, _ in IndexInfo._fields_}
+
+    def knn(self, q, k, order=ORDER_ASCENDING, max_d2=-1.0, want_d2=False):
+        q = _f64(q)
+        idx = np.empty((len(q), k), np.uint32)
+        d2 = np.empty((len(q), k), np.float64) if want_d2 else None
+        _check(lib().pcr_knn(self.ctx.h, self.h, _d(q), len(q), k, order, max_d2, _u(idx), _d(d2)), "pcr_knn")
+        return (idx, d2) if want_d2 else idx
+
+    def knn_d(self, q_t, k, out_idx_t, out_d2_t=None, order=ORDER_ASCENDING, max_d2=-1.0):
+        """Device-resident variant: q_t (nq,3) float64 CUDA tensor, out_idx_t (nq,k) int32/uint32 CUDA tensor."""
+        nq = q_t.shape[0]
+        _check(lib().pcr_knn_d(self.ctx.h, self.h, _vp(q_t.data_ptr()), nq, k, order, max_d2,
+                               _vp(out_idx_t.data_ptr()), _vp(out_d2_t.data_ptr()) if out_d2_t is not None else None),
+               "pcr_knn_d")
+
+    def unique_sq_dist(self):
+        out = C.c_double(0)
+        _check(lib().pcr_unique_sq_dist(self.ctx.h, self.h, C.cast(C.byref(out), _dp)), "pcr_unique_sq_dist")
+        return out.value
+
+    def close(self):
+        if self.h:
+            lib().pcr_index_free(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def icp_step(ctx, src_index, tgt_index, R, T, k, thr_fwd_sq, thr_rev_sq, sample_idx=None, exact=True,
+             want_outputs=True):
+    R, T = _rt(R, T)
+    if sample_idx is not None:
+        sample_idx = np.ascontiguousarray(sample_idx, np.uint32)
+        m = len(sample_idx)
+    else:
+        m = src_index.n
+    partials = np.empty(17)
+    fwd = np.empty(m, np.uint32) if want_outputs else None
+    rev = np.empty(m, np.uint32) if want_outputs else None
+    keep = np.empty(m, np.uint8) if want_outputs else None
+    _check(lib().pcr_icp_step(ctx.h, src_index.h, tgt_index.h, _u(sample_idx), m, _d(R), _d(T), k, thr_fwd_sq,
+                              thr_rev_sq, STEP_EXACT_INDICES if exact else 0, _d(partials), _u(fwd), _u(rev),
+                              _b(keep)), "pcr_icp_step")
+    return dict(partials=partials, fwd=fwd, rev=rev, keep=keep)
+
+
+def icp_step_d(ctx, src_index, tgt_index, R, T, k, thr_fwd_sq, thr_rev_sq, partials_t, sample_begin=0, m=None,
+               sample_idx_t=None, exact=False, out_fwd_t=None, out_rev_t=None, out_keep_t=None):
+    """Asynchronous, device-resident step: partials_t is a float64 CUDA tensor of >= 17 elements."""
+    R, T = _rt(R, T)
+    if m is None:
+        m = sample_idx_t.numel() if sample_idx_t is not None else src_index.n - sample_begin
+
+    def p(t):
+        return _vp(t.data_ptr()) if t is not None else None
+
+    _check(lib().pcr_icp_step_d(ctx.h, src_index.h, tgt_index.h, p(sample_idx_t), sample_begin, m, _d(R), _d(T), k,
+                                thr_fwd_sq, thr_rev_sq, STEP_EXACT_INDICES if exact else 0, p(partials_t),
+                                p(out_fwd_t), p(out_rev_t), p(out_keep_t)), "pcr_icp_step_d")
+
+
+def icp_pivots(src_index, tgt_index, R, T):
+    R, T = _rt(R, T)
+    pp, pq = np.empty(3), np.empty(3)
+    _check(lib().pcr_icp_pivots(src_index.h, tgt_index.h, _d(R), _d(T), _d(pp), _d(pq)), "pcr_icp_pivots")
+    return pp, pq
+
+
+def solve_rigid(partials, pivot_p, pivot_q, R, T):
+    """Returns (R', T', Rc, Tc, mse) -- host-only (3x3 SVD + composition)."""
+    R, T = _rt(R, T)
+    partials = np.ascontiguousarray(partials, np.float64).reshape(17)
+    pivot_p = np.ascontiguousarray(pivot_p, np.float64).reshape(3)
+    pivot_q = np.ascontiguousarray(pivot_q, np.float64).reshape(3)
+    Rc, Tc = np.empty(9), np.empty(3)
+    mse = C.c_double(0)
+    _check(lib().pcr_solve_rigid(_d(partials), _d(pivot_p), _d(pivot_q), _d(R), _d(T), _d(Rc), _d(Tc),
+                                 C.cast(C.byref(mse), _dp)), "pcr_solve_rigid")
+    return R, T, Rc, Tc, mse.value
+
+
+def reject_centroid_dist(ctx, src_index, tgt_index, pair_p, pair_q, msn=25, msd=8.0, cdf=1.0):
+    pp, pq = _f64(pair_p), _f64(pair_q)
+    P = len(pp)
+    keep = np.empty(P, np.uint8)
+    d = np.empty(P)
+    stat = np.empty(2)
+    _check(lib().pcr_reject_centroid_dist(ctx.h, src_index.h, tgt_index.h, _d(pp), _d(pq), P, msn, msd, cdf, _b(keep),
+                                          _d(d), _d(stat)), "pcr_reject_centroid_dist")
+    return dict(keep=keep, d=d, mean=stat[0], sigma=stat[1], kept=int(keep.sum()))

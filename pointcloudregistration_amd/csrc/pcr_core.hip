@@ -1,0 +1,645 @@
+// libpcr.so -- context, clouds, on-device uniform-grid index build (gfx950).
+//
+// Index build = what hiveCommon::CKNNSearch::__buildSearchIndex (Common/KNNSearch.cpp:79-92)
+// does for the KD-tree, re-designed for the GPU: bounds reduction -> cell histogram ->
+// exclusive scan -> scatter into cell order (a counting sort keyed by the linear cell id,
+// x fastest, so the three x-adjacent cells of a row are ONE contiguous candidate range).
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+#include <vector>
+#include "pcr_internal.h"
+
+namespace pcr {
+
+static thread_local char g_last_error[512] = "";
+
+void set_last_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof g_last_error, fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------ bounds
+__global__ void __launch_bounds__(256) bounds_kernel(const double *__restrict__ xyz, uint32_t n,
+                                                     double *__restrict__ out /*[gridDim.x][6]*/) {
+    double lo[3] = {PCR_INF_H, PCR_INF_H, PCR_INF_H}, hi[3] = {-PCR_INF_H, -PCR_INF_H, -PCR_INF_H};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        for (int a = 0; a < 3; ++a) {
+            const double v = xyz[(size_t)i * 3 + a];
+            lo[a] = fmin(lo[a], v);
+            hi[a] = fmax(hi[a], v);
+        }
+    }
+    __shared__ double sm[6][256];
+    for (int a = 0; a < 3; ++a) {
+        sm[a][threadIdx.x] = lo[a];
+        sm[3 + a][threadIdx.x] = hi[a];
+    }
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int a = 0; a < 3; ++a) {
+                sm[a][threadIdx.x] = fmin(sm[a][threadIdx.x], sm[a][threadIdx.x + s]);
+                sm[3 + a][threadIdx.x] = fmax(sm[3 + a][threadIdx.x], sm[3 + a][threadIdx.x + s]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) out[(size_t)blockIdx.x * 6 + threadIdx.x] = sm[threadIdx.x][0];
+}
+
+// ------------------------------------------------------------------ grid build kernels
+struct GridGeom {
+    double lo[3];
+    double inv_h;
+    int g[3];
+};
+
+__device__ __forceinline__ uint32_t cell_of(const GridGeom &G, double x, double y, double z) {
+    double tx = (x - G.lo[0]) * G.inv_h, ty = (y - G.lo[1]) * G.inv_h, tz = (z - G.lo[2]) * G.inv_h;
+    tx = tx < 0.0 ? 0.0 : tx;
+    ty = ty < 0.0 ? 0.0 : ty;
+    tz = tz < 0.0 ? 0.0 : tz;
+    const double mx = (double)(G.g[0] - 1), my = (double)(G.g[1] - 1), mz = (double)(G.g[2] - 1);
+    tx = tx > mx ? mx : tx;
+    ty = ty > my ? my : ty;
+    tz = tz > mz ? mz : tz;
+    return (uint32_t)(((size_t)(int)tz * G.g[1] + (int)ty) * G.g[0] + (int)tx);
+}
+
+__global__ void __launch_bounds__(256) cell_histogram_kernel(const double *__restrict__ xyz, uint32_t n, GridGeom G,
+                                                             uint32_t *__restrict__ counts) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t c = cell_of(G, xyz[(size_t)i * 3], xyz[(size_t)i * 3 + 1], xyz[(size_t)i * 3 + 2]);
+        atomicAdd(&counts[c], 1u);
+    }
+}
+
+constexpr int SCAN_TILE = 4096;  // elements per block (256 threads x 16)
+
+// pass 1: per-tile sum, plus occupancy statistics
+__global__ void __launch_bounds__(256) scan_tile_sums_kernel(const uint32_t *__restrict__ counts, uint64_t cells,
+                                                             uint32_t *__restrict__ tile_sums,
+                                                             unsigned long long *__restrict__ stats /*[2]*/) {
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
+    uint32_t sum = 0, occ = 0, mx = 0;
+    for (int j = 0; j < 16; ++j) {
+        const uint64_t i = base + (uint64_t)j * 256 + threadIdx.x;
+        if (i < cells) {
+            const uint32_t c = counts[i];
+            sum += c;
+            occ += c != 0;
+            mx = max(mx, c);
+        }
+    }
+    __shared__ uint32_t s_sum[256], s_occ[256], s_max[256];
+    s_sum[threadIdx.x] = sum;
+    s_occ[threadIdx.x] = occ;
+    s_max[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            s_sum[threadIdx.x] += s_sum[threadIdx.x + s];
+            s_occ[threadIdx.x] += s_occ[threadIdx.x + s];
+            s_max[threadIdx.x] = max(s_max[threadIdx.x], s_max[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        tile_sums[blockIdx.x] = s_sum[0];
+        atomicAdd(&stats[0], (unsigned long long)s_occ[0]);
+        atomicMax(&stats[1], (unsigned long long)s_max[0]);
+    }
+}
+
+// pass 2: exclusive scan of the tile sums by ONE block (tiles <= 2^30/4096 = 262144)
+__global__ void __launch_bounds__(1024) scan_tile_offsets_kernel(uint32_t *__restrict__ tile_sums, uint32_t tiles) {
+    __shared__ uint32_t sm[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < tiles; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < tiles ? tile_sums[i] : 0;
+        sm[threadIdx.x] = v;
+        __syncthreads();
+        for (int s = 1; s < 1024; s <<= 1) {  // Hillis-Steele inclusive scan
+            const uint32_t add = (int)threadIdx.x >= s ? sm[threadIdx.x - s] : 0;
+            __syncthreads();
+            sm[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const uint32_t incl = sm[threadIdx.x];
+        const uint32_t c = carry;
+        if (i < tiles) tile_sums[i] = c + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + incl;
+        __syncthreads();
+    }
+}
+
+// pass 3: exclusive scan inside each tile, offset by the tile's start; in place (counts -> starts)
+__global__ void __launch_bounds__(256) scan_apply_kernel(uint32_t *__restrict__ counts, uint64_t cells,
+                                                         const uint32_t *__restrict__ tile_offsets, uint32_t total) {
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * 16;
+    uint32_t v[16], sum = 0;
+    for (int j = 0; j < 16; ++j) {
+        v[j] = base + j < cells ? counts[base + j] : 0;
+        sum += v[j];
+    }
+    __shared__ uint32_t sm[256];
+    sm[threadIdx.x] = sum;
+    __syncthreads();
+    for (int s = 1; s < 256; s <<= 1) {
+        const uint32_t add = (int)threadIdx.x >= s ? sm[threadIdx.x - s] : 0;
+        __syncthreads();
+        sm[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = tile_offsets[blockIdx.x] + sm[threadIdx.x] - sum;
+    for (int j = 0; j < 16; ++j) {
+        if (base + j < cells) counts[base + j] = run;
+        run += v[j];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[cells] = total;
+}
+
+__global__ void __launch_bounds__(256) scatter_kernel(const double *__restrict__ xyz, uint32_t n, GridGeom G,
+                                                      uint32_t *__restrict__ cursor, Pt4 *__restrict__ pts) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double x = xyz[(size_t)i * 3], y = xyz[(size_t)i * 3 + 1], z = xyz[(size_t)i * 3 + 2];
+        const uint32_t c = cell_of(G, x, y, z);
+        const uint32_t p = atomicAdd(&cursor[c], 1u);
+        Pt4 o;
+        o.x = x;
+        o.y = y;
+        o.z = z;
+        o.w = i;
+        pts[p] = o;
+    }
+}
+
+// The scatter's atomics leave the order inside a cell to chance.  It cannot change a result (the
+// search orders candidates by (d2, index)), but a fixed layout makes runs reproducible to the byte:
+// order every cell by original index (cells are tiny; huge degenerate cells are left as they are).
+__global__ void __launch_bounds__(256) cell_order_kernel(const uint32_t *__restrict__ cs, uint64_t cells,
+                                                         Pt4 *__restrict__ pts) {
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cells) return;
+    const uint32_t b = cs[c], e = cs[c + 1];
+    if (e - b < 2 || e - b > 256) return;
+    for (uint32_t i = b + 1; i < e; ++i) {
+        const Pt4 v = pts[i];
+        uint32_t j = i;
+        while (j > b && (uint32_t)pts[j - 1].w > (uint32_t)v.w) {
+            pts[j] = pts[j - 1];
+            --j;
+        }
+        pts[j] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) pos_of_kernel(const Pt4 *__restrict__ pts, uint32_t n,
+                                                     uint32_t *__restrict__ pos_of) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pos_of[(uint32_t)pts[i].w] = i;
+}
+
+__global__ void __launch_bounds__(256) pack_kernel(const double *__restrict__ xyz, uint32_t n, Pt4 *__restrict__ pts,
+                                                   uint32_t *__restrict__ pos_of) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        Pt4 o;
+        o.x = xyz[(size_t)i * 3];
+        o.y = xyz[(size_t)i * 3 + 1];
+        o.z = xyz[(size_t)i * 3 + 2];
+        o.w = i;
+        pts[i] = o;
+        pos_of[i] = i;
+    }
+}
+
+static int grid_blocks(uint64_t work, int block = 256, int cap = 2048) {
+    uint64_t b = (work + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > (uint64_t)cap) b = cap;
+    return (int)b;
+}
+
+static int compute_bounds(pcr_ctx *ctx, const double *xyz_d, uint32_t n, double lo[3], double hi[3]) {
+    const int nb = grid_blocks(n, 256, 1024);
+    double *out_d = nullptr;
+    PCR_HIP(hipMalloc(&out_d, sizeof(double) * 6 * nb));
+    hipLaunchKernelGGL(bounds_kernel, dim3(nb), dim3(256), 0, ctx->stream, xyz_d, n, out_d);
+    std::vector<double> h((size_t)6 * nb);
+    hipError_t e = hipMemcpyAsync(h.data(), out_d, sizeof(double) * 6 * nb, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(out_d);
+    PCR_HIP(e);
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = h[a];
+        hi[a] = h[3 + a];
+    }
+    for (int b = 1; b < nb; ++b)
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fmin(lo[a], h[(size_t)b * 6 + a]);
+            hi[a] = fmax(hi[a], h[(size_t)b * 6 + 3 + a]);
+        }
+    return PCR_OK;
+}
+
+}  // namespace pcr
+
+using namespace pcr;
+
+extern "C" {
+
+const char *pcr_strerror(int s) {
+    switch (s) {
+        case PCR_OK: return "ok";
+        case PCR_E_INVALID: return "invalid argument";
+        case PCR_E_HIP: return "HIP runtime error";
+        case PCR_E_NOMEM: return "out of memory";
+        case PCR_E_UNSUPPORTED: return "unsupported";
+        case PCR_E_EMPTY: return "no correspondence survived the gates";
+        case PCR_E_NO_DEVICE: return "no usable gfx950 device";
+        default: return "unknown status";
+    }
+}
+
+const char *pcr_last_error(void) { return g_last_error; }
+
+const char *pcr_version(void) { return "libpcr 0.1 (gfx950, fp64, -ffp-contract=off)"; }
+
+int pcr_ctx_create(int device, void *hip_stream, pcr_ctx **out) {
+    PCR_REQUIRE(out, "pcr_ctx_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        set_last_error("pcr_ctx_create: no HIP device visible");
+        return PCR_E_NO_DEVICE;
+    }
+    PCR_REQUIRE(device >= 0 && device < count, "pcr_ctx_create: device %d out of range [0,%d)", device, count);
+    PCR_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    PCR_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_last_error("pcr_ctx_create: device %d is %s; this library holds gfx950 code only", device,
+                       prop.gcnArchName);
+        return PCR_E_NO_DEVICE;
+    }
+    pcr_ctx *c = new pcr_ctx();
+    c->device = device;
+    c->own_stream = hip_stream == nullptr;
+    c->stream = (hipStream_t)hip_stream;
+    c->block_partials_d = nullptr;
+    c->block_partials_cap = 0;
+    c->result_d = nullptr;
+    c->result_h = nullptr;
+    if (c->own_stream) {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            PCR_HIP(e);
+        }
+    }
+    hipError_t e = hipMalloc(&c->result_d, sizeof(double) * 32);
+    if (e == hipSuccess) e = hipHostMalloc(&c->result_h, sizeof(double) * 32, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        pcr_ctx_destroy(c);
+        PCR_HIP(e);
+    }
+    *out = c;
+    return PCR_OK;
+}
+
+int pcr_ctx_destroy(pcr_ctx *c) {
+    if (!c) return PCR_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->block_partials_d) hipFree(c->block_partials_d);
+    if (c->result_d) hipFree(c->result_d);
+    if (c->result_h) hipHostFree(c->result_h);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return PCR_OK;
+}
+
+int pcr_ctx_synchronize(pcr_ctx *c) {
+    PCR_REQUIRE(c, "pcr_ctx_synchronize: ctx is NULL");
+    PCR_HIP(hipSetDevice(c->device));
+    PCR_HIP(hipStreamSynchronize(c->stream));
+    return PCR_OK;
+}
+
+static int cloud_finish(pcr_ctx *ctx, pcr_cloud *c) {
+    if (c->n == 0) {
+        for (int a = 0; a < 3; ++a) c->lo[a] = c->hi[a] = 0.0;
+        return PCR_OK;
+    }
+    return compute_bounds(ctx, c->xyz_d, c->n, c->lo, c->hi);
+}
+
+int pcr_cloud_upload(pcr_ctx *ctx, const double *xyz, uint32_t n, pcr_cloud **out) {
+    PCR_REQUIRE(ctx && out, "pcr_cloud_upload: NULL argument");
+    *out = nullptr;
+    PCR_REQUIRE(xyz || n == 0, "pcr_cloud_upload: xyz is NULL with n=%u", n);
+    PCR_HIP(hipSetDevice(ctx->device));
+    double *d = nullptr;
+    if (n) {
+        PCR_HIP(hipMalloc(&d, sizeof(double) * 3 * (size_t)n));
+        hipError_t e = hipMemcpyAsync(d, xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            hipFree(d);
+            PCR_HIP(e);
+        }
+    }
+    pcr_cloud *c = new pcr_cloud();
+    c->ctx = ctx;
+    c->n = n;
+    c->xyz_d = d;
+    c->owned = true;
+    int rc = cloud_finish(ctx, c);
+    if (rc != PCR_OK) {
+        pcr_cloud_free(c);
+        return rc;
+    }
+    *out = c;
+    return PCR_OK;
+}
+
+int pcr_cloud_wrap_d(pcr_ctx *ctx, const double *xyz_d, uint32_t n, pcr_cloud **out) {
+    PCR_REQUIRE(ctx && out, "pcr_cloud_wrap_d: NULL argument");
+    *out = nullptr;
+    PCR_REQUIRE(xyz_d || n == 0, "pcr_cloud_wrap_d: xyz_d is NULL with n=%u", n);
+    PCR_HIP(hipSetDevice(ctx->device));
+    pcr_cloud *c = new pcr_cloud();
+    c->ctx = ctx;
+    c->n = n;
+    c->xyz_d = xyz_d;
+    c->owned = false;
+    int rc = cloud_finish(ctx, c);
+    if (rc != PCR_OK) {
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return PCR_OK;
+}
+
+int pcr_cloud_free(pcr_cloud *c) {
+    if (!c) return PCR_OK;
+    hipSetDevice(c->ctx->device);
+    if (c->owned && c->xyz_d) hipFree(const_cast<double *>(c->xyz_d));
+    delete c;
+    return PCR_OK;
+}
+
+uint32_t pcr_cloud_size(const pcr_cloud *c) { return c ? c->n : 0; }
+
+int pcr_cloud_bounds(const pcr_cloud *c, double lo[3], double hi[3]) {
+    PCR_REQUIRE(c && lo && hi, "pcr_cloud_bounds: NULL argument");
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = c->lo[a];
+        hi[a] = c->hi[a];
+    }
+    return PCR_OK;
+}
+
+int pcr_index_free(pcr_index *ix) {
+    if (!ix) return PCR_OK;
+    hipSetDevice(ix->ctx->device);
+    if (ix->pts_d) hipFree(ix->pts_d);
+    if (ix->tpts_d) hipFree(ix->tpts_d);
+    if (ix->cs_d) hipFree(ix->cs_d);
+    if (ix->pos_of_d) hipFree(ix->pos_of_d);
+    delete ix;
+    return PCR_OK;
+}
+
+// one trial of the histogram at a given cell size: fills counts (device) and returns statistics
+static int histogram_trial(pcr_ctx *ctx, const pcr_cloud *cloud, const GridGeom &G, uint64_t cells,
+                           uint32_t *counts_d, uint32_t *tile_sums_d, unsigned long long *stats_d,
+                           unsigned long long stats_h[2]) {
+    PCR_HIP(hipMemsetAsync(counts_d, 0, sizeof(uint32_t) * (cells + 1), ctx->stream));
+    PCR_HIP(hipMemsetAsync(stats_d, 0, sizeof(unsigned long long) * 2, ctx->stream));
+    hipLaunchKernelGGL(cell_histogram_kernel, dim3(grid_blocks(cloud->n)), dim3(256), 0, ctx->stream, cloud->xyz_d,
+                       cloud->n, G, counts_d);
+    const uint32_t tiles = (uint32_t)((cells + SCAN_TILE - 1) / SCAN_TILE);
+    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(tiles), dim3(256), 0, ctx->stream, counts_d, cells, tile_sums_d,
+                       stats_d);
+    PCR_HIP(hipMemcpyAsync(stats_h, stats_d, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(hipStreamSynchronize(ctx->stream));
+    return PCR_OK;
+}
+
+static void make_geom(const pcr_cloud *cloud, double h, uint64_t max_cells, GridGeom &G, double &h_out,
+                      uint64_t &cells) {
+    for (;;) {
+        cells = 1;
+        for (int a = 0; a < 3; ++a) {
+            const double ext = cloud->hi[a] - cloud->lo[a];
+            double g = floor(ext / h) + 1.0;
+            if (!(g >= 1.0)) g = 1.0;
+            if (g > 2097152.0) g = 2097152.0;
+            G.g[a] = (int)g;
+            G.lo[a] = cloud->lo[a];
+            cells *= (uint64_t)G.g[a];
+        }
+        if (cells <= max_cells) break;
+        h *= 1.26;  // ~ cube root of 2: halves the cell count of a volume per step
+    }
+    G.inv_h = 1.0 / h;
+    h_out = h;
+}
+
+int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params *params, pcr_index **out) {
+    PCR_REQUIRE(ctx && cloud && out, "pcr_index_build: NULL argument");
+    *out = nullptr;
+    PCR_REQUIRE(cloud->n > 0, "pcr_index_build: empty cloud");
+    PCR_REQUIRE(cloud->ctx == ctx, "pcr_index_build: cloud belongs to another context");
+    for (int a = 0; a < 3; ++a)
+        PCR_REQUIRE(isfinite(cloud->lo[a]) && isfinite(cloud->hi[a]), "pcr_index_build: non-finite coordinates");
+    PCR_HIP(hipSetDevice(ctx->device));
+    pcr_index_params P;
+    memset(&P, 0, sizeof P);
+    if (params) P = *params;
+    if (!(P.target_occupancy > 0)) P.target_occupancy = 2.0;
+    if (P.max_cells == 0) P.max_cells = 1ull << 30;
+    if (P.max_cells > (1ull << 32) - 8) P.max_cells = (1ull << 32) - 8;
+    if (P.brute_max_points == 0) P.brute_max_points = 2048;
+    int kind = P.kind;
+    PCR_REQUIRE(kind == PCR_INDEX_AUTO || kind == PCR_INDEX_GRID || kind == PCR_INDEX_BRUTE,
+                "pcr_index_build: unknown kind %d", kind);
+    if (kind == PCR_INDEX_AUTO) kind = cloud->n <= P.brute_max_points ? PCR_INDEX_BRUTE : PCR_INDEX_GRID;
+
+    const uint32_t n = cloud->n;
+    pcr_index *ix = new pcr_index();
+    memset(ix, 0, sizeof *ix);
+    ix->ctx = ctx;
+    ix->cloud = cloud;
+    ix->kind = kind;
+    ix->n = n;
+    int rc = PCR_OK;
+    uint32_t *counts_d = nullptr, *tile_sums_d = nullptr, *cursor_d = nullptr;
+    unsigned long long *stats_d = nullptr;
+#define BUILD_HIP(call)                                                                             \
+    do {                                                                                            \
+        hipError_t e__ = (call);                                                                    \
+        if (e__ != hipSuccess) {                                                                    \
+            set_last_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+            rc = e__ == hipErrorOutOfMemory ? PCR_E_NOMEM : PCR_E_HIP;                             \
+            goto fail;                                                                              \
+        }                                                                                           \
+    } while (0)
+
+    BUILD_HIP(hipMalloc(&ix->pts_d, sizeof(Pt4) * (size_t)n));
+    BUILD_HIP(hipMalloc(&ix->tpts_d, sizeof(Pt4) * (size_t)n));
+    BUILD_HIP(hipMalloc(&ix->pos_of_d, sizeof(uint32_t) * (size_t)n));
+
+    {
+        GridView &V = ix->view;
+        double scale = 0, maxext = 0;
+        for (int a = 0; a < 3; ++a) {
+            V.lo[a] = cloud->lo[a];
+            V.hi[a] = cloud->hi[a];
+            scale = fmax(scale, fmax(fabs(cloud->lo[a]), fabs(cloud->hi[a])));
+            maxext = fmax(maxext, cloud->hi[a] - cloud->lo[a]);
+        }
+        V.margin = 9.094947017729282e-13 * (scale + maxext);  // 2^-40 of the coordinate scale
+        V.n = n;
+        V.pts = ix->pts_d;
+        V.cs = nullptr;
+        V.h = V.inv_h = 1.0;
+        V.g[0] = V.g[1] = V.g[2] = 1;
+
+        if (kind == PCR_INDEX_BRUTE) {
+            hipLaunchKernelGGL(pack_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, cloud->xyz_d, n,
+                               ix->pts_d, ix->pos_of_d);
+            BUILD_HIP(hipStreamSynchronize(ctx->stream));
+            ix->info.kind = kind;
+            ix->info.n = n;
+            ix->info.dims[0] = ix->info.dims[1] = ix->info.dims[2] = 1;
+            ix->info.cells = ix->info.occupied_cells = 1;
+            ix->info.cell_size = 0;
+            ix->info.mean_occupancy = n;
+            ix->info.max_occupancy = n;
+            ix->info.device_bytes = (sizeof(Pt4) * 2 + 4) * (uint64_t)n;
+            *out = ix;
+            return PCR_OK;
+        }
+
+        // ---- choose the cell edge: aim at target_occupancy points per OCCUPIED cell ----
+        double ext[3], vol = 1.0;
+        int live = 0;
+        for (int a = 0; a < 3; ++a) {
+            ext[a] = cloud->hi[a] - cloud->lo[a];
+            if (ext[a] > 0) {
+                vol *= ext[a];
+                ++live;
+            }
+        }
+        double h;
+        if (P.cell_size > 0)
+            h = P.cell_size;
+        else if (live == 0)
+            h = 1.0;
+        else
+            h = pow(vol * P.target_occupancy / (double)n, 1.0 / live);  // volume-uniform first guess
+        if (!(h > 0) || !isfinite(h)) h = 1.0;
+        // never finer than 2^-20 of the scale: keeps the safety margin (2^-40) far below a cell
+        const double h_min = (scale + maxext) * 9.5367431640625e-07;
+        if (h < h_min) h = h_min > 0 ? h_min : 1.0;
+
+        GridGeom G;
+        uint64_t cells = 0;
+        unsigned long long stats_h[2] = {0, 0};
+        BUILD_HIP(hipMalloc(&stats_d, sizeof(unsigned long long) * 2));
+        size_t counts_cap = 0;
+        for (int trial = 0; trial < 8; ++trial) {
+            double h_used;
+            make_geom(cloud, h, P.max_cells, G, h_used, cells);
+            h = h_used;
+            if (cells + 1 > counts_cap) {
+                if (counts_d) hipFree(counts_d);
+                if (tile_sums_d) hipFree(tile_sums_d);
+                counts_d = tile_sums_d = nullptr;
+                counts_cap = cells + 1;
+                BUILD_HIP(hipMalloc(&counts_d, sizeof(uint32_t) * counts_cap));
+                BUILD_HIP(hipMalloc(&tile_sums_d, sizeof(uint32_t) * ((cells + SCAN_TILE - 1) / SCAN_TILE + 1)));
+            }
+            rc = histogram_trial(ctx, cloud, G, cells, counts_d, tile_sums_d, stats_d, stats_h);
+            if (rc != PCR_OK) goto fail;
+            if (P.cell_size > 0) break;
+            const double occ = (double)n / (double)(stats_h[0] ? stats_h[0] : 1);
+            const double ratio = P.target_occupancy / occ;
+            if (ratio < 1.35 && ratio > 0.74) break;  // close enough
+            if (ratio < 1.0 && cells == 1) break;
+            // points on a surface: occupancy ~ h^2.  (A volume converges too, in a damped oscillation.)
+            double nh = h * sqrt(ratio);
+            if (nh < h_min) nh = h_min;
+            if (nh == h) break;
+            // growing h is always possible; shrinking may hit max_cells, in which case make_geom undoes it
+            if (trial == 7) break;
+            h = nh;
+        }
+
+        // ---- scan + scatter ----
+        {
+            const uint32_t tiles = (uint32_t)((cells + SCAN_TILE - 1) / SCAN_TILE);
+            hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, tile_sums_d, tiles);
+            hipLaunchKernelGGL(scan_apply_kernel, dim3(tiles), dim3(256), 0, ctx->stream, counts_d, cells,
+                               tile_sums_d, n);
+            BUILD_HIP(hipMalloc(&cursor_d, sizeof(uint32_t) * cells));
+            BUILD_HIP(hipMemcpyAsync(cursor_d, counts_d, sizeof(uint32_t) * cells, hipMemcpyDeviceToDevice,
+                                     ctx->stream));
+            hipLaunchKernelGGL(scatter_kernel, dim3(grid_blocks(n)), dim3(256), 0, ctx->stream, cloud->xyz_d, n, G,
+                               cursor_d, ix->pts_d);
+            hipLaunchKernelGGL(cell_order_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream,
+                               counts_d, cells, ix->pts_d);
+            hipLaunchKernelGGL(pos_of_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ix->pts_d, n,
+                               ix->pos_of_d);
+            BUILD_HIP(hipStreamSynchronize(ctx->stream));
+            BUILD_HIP(hipGetLastError());
+        }
+        ix->cs_d = counts_d;
+        counts_d = nullptr;
+        V.cs = ix->cs_d;
+        V.h = h;
+        V.inv_h = G.inv_h;
+        for (int a = 0; a < 3; ++a) V.g[a] = G.g[a];
+        ix->info.kind = kind;
+        ix->info.n = n;
+        for (int a = 0; a < 3; ++a) ix->info.dims[a] = (uint32_t)G.g[a];
+        ix->info.cells = cells;
+        ix->info.occupied_cells = stats_h[0];
+        ix->info.cell_size = h;
+        ix->info.mean_occupancy = (double)n / (double)(stats_h[0] ? stats_h[0] : 1);
+        ix->info.max_occupancy = (uint32_t)stats_h[1];
+        ix->info.device_bytes = (sizeof(Pt4) * 2 + 4) * (uint64_t)n + 4 * (cells + 1);
+    }
+    if (tile_sums_d) hipFree(tile_sums_d);
+    if (cursor_d) hipFree(cursor_d);
+    if (stats_d) hipFree(stats_d);
+    *out = ix;
+    return PCR_OK;
+
+fail:
+    if (counts_d) hipFree(counts_d);
+    if (tile_sums_d) hipFree(tile_sums_d);
+    if (cursor_d) hipFree(cursor_d);
+    if (stats_d) hipFree(stats_d);
+    pcr_index_free(ix);
+    return rc;
+#undef BUILD_HIP
+}
+
+int pcr_index_get_info(const pcr_index *ix, pcr_index_info *info) {
+    PCR_REQUIRE(ix && info, "pcr_index_get_info: NULL argument");
+    *info = ix->info;
+    return PCR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,83 @@
+// Internal declarations shared by the translation units of libpcr.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/pcr.h"
+
+#define PCR_INF_H __builtin_huge_val()
+
+namespace pcr {
+
+void set_last_error(const char *fmt, ...);
+
+#define PCR_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (call);                                                               \
+        if (e__ != hipSuccess) {                                                               \
+            ::pcr::set_last_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__),      \
+                                  __FILE__, __LINE__);                                         \
+            return e__ == hipErrorOutOfMemory ? PCR_E_NOMEM : PCR_E_HIP;                       \
+        }                                                                                      \
+    } while (0)
+
+#define PCR_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            ::pcr::set_last_error(__VA_ARGS__); \
+            return PCR_E_INVALID;              \
+        }                                      \
+    } while (0)
+
+// One point of a cell-sorted cloud: x, y, z and the ORIGINAL index in the low 32 bits of w.
+// 32 bytes, so a candidate is two 16-byte loads from one aligned line segment.
+struct __attribute__((aligned(32))) Pt4 {
+    double x, y, z;
+    unsigned long long w;
+};
+
+// What the query kernels need to know about an index (passed by value).
+struct GridView {
+    const Pt4 *pts;       // [n] in cell order (GRID) or in original order (BRUTE)
+    const uint32_t *cs;   // [cells+1] exclusive cell starts; NULL for BRUTE
+    double lo[3], hi[3];  // bounds of the points
+    double h, inv_h;      // cell edge
+    double margin;        // absolute safety margin on face distances, ~2^-40 * coordinate scale
+    int g[3];             // grid dimensions
+    uint32_t n;
+};
+
+}  // namespace pcr
+
+struct pcr_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    // reusable device scratch for block partials of the fused step (grown on demand, never per call
+    // once warm) and a pinned host staging area for the 17 results.
+    double *block_partials_d;
+    size_t block_partials_cap;  // in doubles
+    double *result_d;           // [32] device
+    double *result_h;           // [32] pinned host
+};
+
+struct pcr_cloud {
+    pcr_ctx *ctx;
+    uint32_t n;
+    const double *xyz_d;  // AoS [3n]
+    bool owned;
+    double lo[3], hi[3];
+};
+
+struct pcr_index {
+    pcr_ctx *ctx;
+    const pcr_cloud *cloud;
+    int kind;  // PCR_INDEX_GRID or PCR_INDEX_BRUTE
+    uint32_t n;
+    pcr::Pt4 *pts_d;    // [n] cell order (GRID) / original order (BRUTE)
+    pcr::Pt4 *tpts_d;   // [n] same order, transformed by the current (R,T) -- scratch of the ICP step
+    uint32_t *cs_d;     // [cells+1]
+    uint32_t *pos_of_d; // [n] original index -> position in pts_d
+    pcr::GridView view;
+    pcr_index_info info;
+};

@@ -1,0 +1,190 @@
+// libpcr.so -- batched exact K-NN entry points (gfx950).
+//
+// Replaces hiveCommon::CKNNSearch::executeKNN (Common/KNNSearch.cpp:65-75, one query per call,
+// serial tree descent) and hiveSearch::CKNNSearch::_executeSearchV (NewKNNSearch.cpp:32-54,
+// OpenMP over queries) with one launch over all queries: one lane per query walking the
+// uniform grid, or -- for small clouds -- a tiled brute-force scan with LDS-staged tiles.
+#include <math.h>
+#include <vector>
+#include "knn_device.h"
+
+namespace pcr {
+
+template <int KC>
+__device__ __forceinline__ void write_result(const TopK<KC> &top, int k, int order, double max_d2, uint32_t *oi,
+                                             double *od) {
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+        if (j < k) {
+            const bool ok = top.d[j] < max_d2;
+            const int o = order == PCR_ORDER_DESCENDING ? k - 1 - j : j;
+            oi[o] = ok ? top.idx[j] : PCR_NO_INDEX;
+            if (od) od[o] = ok ? top.d[j] : PCR_INF;
+        }
+    }
+}
+
+template <int KC>
+__global__ void __launch_bounds__(256) knn_grid_kernel(GridView g, const double *__restrict__ q, uint32_t nq, int k,
+                                                       int order, double max_d2, uint32_t *__restrict__ out_idx,
+                                                       double *__restrict__ out_d2) {
+    const uint32_t i = xcd_remap(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
+    if (i >= nq) return;
+    const double qx = q[(size_t)i * 3], qy = q[(size_t)i * 3 + 1], qz = q[(size_t)i * 3 + 2];
+    TopK<KC> top;
+    top.init(max_d2);
+    if (isfinite(qx) && isfinite(qy) && isfinite(qz))
+        grid_search<KC>(g, g.pts, qx, qy, qz, qx, qy, qz, max_d2, 1.0 - 1.8189894035458565e-12, 0.0, top);
+    write_result<KC>(top, k, order, max_d2, out_idx + (size_t)i * k, out_d2 ? out_d2 + (size_t)i * k : nullptr);
+}
+
+constexpr int BRUTE_TILE = 512;  // points per LDS tile: 16 KiB
+
+template <int KC>
+__global__ void __launch_bounds__(256) knn_brute_kernel(const Pt4 *__restrict__ pts, uint32_t n,
+                                                        const double *__restrict__ q, uint32_t nq, int k, int order,
+                                                        double max_d2, uint32_t *__restrict__ out_idx,
+                                                        double *__restrict__ out_d2) {
+    __shared__ Pt4 tile[BRUTE_TILE];
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool live = i < nq;
+    double qx = 0, qy = 0, qz = 0;
+    if (live) {
+        qx = q[(size_t)i * 3];
+        qy = q[(size_t)i * 3 + 1];
+        qz = q[(size_t)i * 3 + 2];
+    }
+    const bool fin = isfinite(qx) && isfinite(qy) && isfinite(qz);
+    TopK<KC> top;
+    top.init(max_d2);
+    for (uint32_t base = 0; base < n; base += BRUTE_TILE) {
+        const int cnt = (int)min((uint32_t)BRUTE_TILE, n - base);
+        for (int t = threadIdx.x; t < cnt; t += 256) tile[t] = pts[base + t];  // coalesced 32-B rows
+        __syncthreads();
+        if (live && fin) tile_scan<KC>(tile, cnt, base, qx, qy, qz, top);
+        __syncthreads();
+    }
+    if (live)
+        write_result<KC>(top, k, order, max_d2, out_idx + (size_t)i * k, out_d2 ? out_d2 + (size_t)i * k : nullptr);
+}
+
+__global__ void gather_rows_kernel(const double *__restrict__ xyz, uint32_t first, uint32_t stride, uint32_t count,
+                                   double *__restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < count * 3) out[t] = xyz[(size_t)(first + (t / 3) * stride) * 3 + t % 3];
+}
+
+template <int KC>
+static void launch_knn(pcr_ctx *ctx, const pcr_index *ix, const double *q_d, uint32_t nq, uint32_t k, int order,
+                       double max_d2, uint32_t *oi_d, double *od_d) {
+    const uint32_t nb = (nq + 255) / 256;
+    if (ix->kind == PCR_INDEX_GRID)
+        hipLaunchKernelGGL(knn_grid_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, ix->view, q_d, nq, (int)k, order,
+                           max_d2, oi_d, od_d);
+    else
+        hipLaunchKernelGGL(knn_brute_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, ix->pts_d, ix->n, q_d, nq,
+                           (int)k, order, max_d2, oi_d, od_d);
+}
+
+}  // namespace pcr
+
+using namespace pcr;
+
+extern "C" {
+
+int pcr_knn_d(pcr_ctx *ctx, const pcr_index *ix, const double *q_d, uint32_t nq, uint32_t k, int order, double max_d2,
+              uint32_t *out_idx_d, double *out_d2_d) {
+    PCR_REQUIRE(ctx && ix && out_idx_d, "pcr_knn_d: NULL argument");
+    PCR_REQUIRE(ix->ctx == ctx, "pcr_knn_d: index belongs to another context");
+    PCR_REQUIRE(k >= 1, "pcr_knn_d: k must be >= 1");
+    PCR_REQUIRE(k <= ix->n, "pcr_knn_d: k=%u exceeds the %u indexed points (Common/KNNSearch.cpp:19)", k, ix->n);
+    if (k > PCR_MAX_K) {
+        set_last_error("pcr_knn_d: k=%u above PCR_MAX_K=%u", k, PCR_MAX_K);
+        return PCR_E_UNSUPPORTED;
+    }
+    PCR_REQUIRE(order == PCR_ORDER_ASCENDING || order == PCR_ORDER_DESCENDING, "pcr_knn_d: bad order %d", order);
+    if (nq == 0) return PCR_OK;
+    PCR_REQUIRE(q_d, "pcr_knn_d: q_d is NULL");
+    PCR_HIP(hipSetDevice(ctx->device));
+    if (!(max_d2 >= 0) || isinf(max_d2)) max_d2 = PCR_INF_H;  // negative / NaN / inf: unbounded
+    if (k == 1)
+        launch_knn<1>(ctx, ix, q_d, nq, k, order, max_d2, out_idx_d, out_d2_d);
+    else if (k <= 4)
+        launch_knn<4>(ctx, ix, q_d, nq, k, order, max_d2, out_idx_d, out_d2_d);
+    else if (k <= 8)
+        launch_knn<8>(ctx, ix, q_d, nq, k, order, max_d2, out_idx_d, out_d2_d);
+    else if (k <= 16)
+        launch_knn<16>(ctx, ix, q_d, nq, k, order, max_d2, out_idx_d, out_d2_d);
+    else
+        launch_knn<32>(ctx, ix, q_d, nq, k, order, max_d2, out_idx_d, out_d2_d);
+    PCR_HIP(hipGetLastError());
+    return PCR_OK;
+}
+
+int pcr_knn(pcr_ctx *ctx, const pcr_index *ix, const double *q, uint32_t nq, uint32_t k, int order, double max_d2,
+            uint32_t *out_idx, double *out_d2) {
+    PCR_REQUIRE(ctx && ix && out_idx, "pcr_knn: NULL argument");
+    if (nq == 0) return pcr_knn_d(ctx, ix, nullptr, 0, k, order, max_d2, out_idx, nullptr);
+    PCR_REQUIRE(q, "pcr_knn: q is NULL");
+    PCR_HIP(hipSetDevice(ctx->device));
+    double *q_d = nullptr, *od_d = nullptr;
+    uint32_t *oi_d = nullptr;
+    int rc = PCR_OK;
+    hipError_t e = hipMalloc(&q_d, sizeof(double) * 3 * (size_t)nq);
+    if (e == hipSuccess) e = hipMalloc(&oi_d, sizeof(uint32_t) * (size_t)nq * k);
+    if (e == hipSuccess && out_d2) e = hipMalloc(&od_d, sizeof(double) * (size_t)nq * k);
+    if (e == hipSuccess) e = hipMemcpyAsync(q_d, q, sizeof(double) * 3 * (size_t)nq, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        rc = pcr_knn_d(ctx, ix, q_d, nq, k, order, max_d2, oi_d, od_d);
+        if (rc == PCR_OK) {
+            e = hipMemcpyAsync(out_idx, oi_d, sizeof(uint32_t) * (size_t)nq * k, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess && out_d2)
+                e = hipMemcpyAsync(out_d2, od_d, sizeof(double) * (size_t)nq * k, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        }
+    }
+    if (q_d) hipFree(q_d);
+    if (oi_d) hipFree(oi_d);
+    if (od_d) hipFree(od_d);
+    if (rc != PCR_OK) return rc;
+    PCR_HIP(e);
+    return PCR_OK;
+}
+
+int pcr_unique_sq_dist(pcr_ctx *ctx, const pcr_index *ix, double *out) {
+    PCR_REQUIRE(ctx && ix && out, "pcr_unique_sq_dist: NULL argument");
+    PCR_REQUIRE(ix->n >= 4, "pcr_unique_sq_dist: needs >= 4 points (K=4, UniqueData.cpp:34)");
+    PCR_HIP(hipSetDevice(ctx->device));
+    // UniqueData.cpp:29-31,40-50: SampleDist = max(1, N/20); SampleItr = 0, SampleDist, ... < N
+    uint32_t stride = ix->n / 20;
+    if (stride < 1) stride = 1;
+    const uint32_t count = (ix->n + stride - 1) / stride;
+    double *q_d = nullptr, *d_d = nullptr;
+    uint32_t *i_d = nullptr;
+    hipError_t e = hipMalloc(&q_d, sizeof(double) * 3 * count);
+    if (e == hipSuccess) e = hipMalloc(&d_d, sizeof(double) * 4 * count);
+    if (e == hipSuccess) e = hipMalloc(&i_d, sizeof(uint32_t) * 4 * count);
+    int rc = PCR_OK;
+    std::vector<double> d2((size_t)count * 4);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((count * 3 + 255) / 256), dim3(256), 0, ctx->stream,
+                           ix->cloud->xyz_d, 0u, stride, count, q_d);
+        rc = pcr_knn_d(ctx, ix, q_d, count, 4, PCR_ORDER_ASCENDING, -1.0, i_d, d_d);
+        if (rc == PCR_OK) {
+            e = hipMemcpyAsync(d2.data(), d_d, sizeof(double) * 4 * count, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        }
+    }
+    if (q_d) hipFree(q_d);
+    if (d_d) hipFree(d_d);
+    if (i_d) hipFree(i_d);
+    if (rc != PCR_OK) return rc;
+    PCR_HIP(e);
+    double sum = 0;  // same order as the reference: sample by sample, neighbour 0..3 (:43-46)
+    for (uint32_t s = 0; s < count; ++s)
+        for (int j = 0; j < 4; ++j) sum += d2[(size_t)s * 4 + j];
+    *out = sum / (count * 4);
+    return PCR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,221 @@
+// libpcr.so -- CRejectionCentroidDist on the device (gfx950).
+//
+// Replaces CRejectionCentroidDist::_rejectInvalidPairsV and its helpers
+// (PointCloudRegistration/RejectionCentroidDist.cpp:23-208; RegMath.h:11-22,42-55,64-67).
+// The class is orphan code in the reference (compiled, never registered: SURVEY.md 0-7); its
+// behaviour is reproduced INCLUDING its quirks, because "results identical to the reference" is
+// the bar:
+//   * "centroid" = (x + sum of neighbours) with ONLY component 0 divided, three times, by
+//     (count+1); components 1 and 2 stay undivided sums                        (:103-115)
+//   * the source-side query uses the TRANSFORMED source point against the index of the
+//     UNTRANSFORMED source cloud                                               (:52,:75)
+//   * MSD is compared with a SQUARED distance; the neighbour list is cut at the first entry with
+//     d2 >= MSD (std::lower_bound on the ascending list)                       (:165-176,200-208)
+// Per pair: two exact K-NN searches with K = MSN (one lane per pair, top-K in registers), the
+// statistic d_i = |s_tgt - s_src|; then mean, population sigma (two fixed-order tree reductions)
+// and the mask |d_i - mean| <= CDF * sigma.
+#include <math.h>
+#include <vector>
+#include "knn_device.h"
+
+namespace pcr {
+
+template <int KC>
+__device__ __forceinline__ double sq_dist_to_centroid(const GridView &g, double x, double y, double z, int k,
+                                                      double msd) {
+    TopK<KC> top;
+    top.init();
+    if (isfinite(x) && isfinite(y) && isfinite(z))
+        grid_search<KC>(g, g.pts, x, y, z, x, y, z, PCR_INF, 1.0 - 1.8189894035458565e-12, 0.0, top);
+    double c0 = x, c1 = y, c2 = z;
+    int cnt = 0;
+    bool open = true;  // prefix of the ascending list with d2 < MSD
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+        if (j < k) {
+            open = open && top.idx[j] != PCR_NO_INDEX && top.d[j] < msd;
+            if (open) {
+                const Pt4 p = g.pts[top.pos[j]];
+                c0 += p.x;
+                c1 += p.y;
+                c2 += p.z;
+                ++cnt;
+            }
+        }
+    }
+    const double den = (double)(cnt + 1);
+    c0 /= den;
+    c0 /= den;
+    c0 /= den;
+    return sqdist3(x, y, z, c0, c1, c2);
+}
+
+template <int KC>
+__global__ void __launch_bounds__(256) reject_stat_kernel(GridView src, GridView tgt, const double *__restrict__ pp,
+                                                          const double *__restrict__ pq, uint32_t P, int k,
+                                                          double msd, double *__restrict__ d_out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= P) return;
+    double s[2];
+    // one instance of the search code, run twice (target side first, as the reference does, :74-75)
+#pragma nounroll
+    for (int side = 0; side < 2; ++side) {
+        const GridView &g = side ? src : tgt;
+        const double *x = (side ? pp : pq) + (size_t)i * 3;
+        s[side] = sq_dist_to_centroid<KC>(g, x[0], x[1], x[2], k, msd);
+    }
+    d_out[i] = fabs(s[0] - s[1]);  // (:77)
+}
+
+// brute-force flavour for BRUTE indices: one lane per pair, plain global scan (small clouds only)
+template <int KC>
+__device__ __forceinline__ double sq_dist_to_centroid_brute(const GridView &g, double x, double y, double z, int k,
+                                                            double msd) {
+    TopK<KC> top;
+    top.init();
+    double wd = PCR_INF;
+    uint32_t wi = PCR_NO_INDEX;
+    for (uint32_t j = 0; j < g.n; ++j) {
+        const Pt4 c = g.pts[j];
+        const double d = sqdist3(x, y, z, c.x, c.y, c.z);
+        if (better(d, (uint32_t)c.w, wd, wi)) {
+            top.insert(d, (uint32_t)c.w, j);
+            wd = top.worst_d();
+            wi = top.worst_i();
+        }
+    }
+    double c0 = x, c1 = y, c2 = z;
+    int cnt = 0;
+    bool open = true;
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+        if (j < k) {
+            open = open && top.idx[j] != PCR_NO_INDEX && top.d[j] < msd;
+            if (open) {
+                const Pt4 p = g.pts[top.pos[j]];
+                c0 += p.x;
+                c1 += p.y;
+                c2 += p.z;
+                ++cnt;
+            }
+        }
+    }
+    const double den = (double)(cnt + 1);
+    c0 /= den;
+    c0 /= den;
+    c0 /= den;
+    return sqdist3(x, y, z, c0, c1, c2);
+}
+
+template <int KC>
+__global__ void __launch_bounds__(256) reject_stat_brute_kernel(GridView src, GridView tgt,
+                                                                const double *__restrict__ pp,
+                                                                const double *__restrict__ pq, uint32_t P, int k,
+                                                                double msd, double *__restrict__ d_out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= P) return;
+    const double st = sq_dist_to_centroid_brute<KC>(tgt, pq[(size_t)i * 3], pq[(size_t)i * 3 + 1], pq[(size_t)i * 3 + 2], k, msd);
+    const double ss = sq_dist_to_centroid_brute<KC>(src, pp[(size_t)i * 3], pp[(size_t)i * 3 + 1], pp[(size_t)i * 3 + 2], k, msd);
+    d_out[i] = fabs(st - ss);
+}
+
+// out[0] = sum_i f(d_i), f = identity (center == NULL) or (d - *center)^2.  One block, fixed order.
+__global__ void __launch_bounds__(1024) sum_kernel(const double *__restrict__ d, uint32_t P,
+                                                   const double *__restrict__ center, double divisor,
+                                                   double *__restrict__ out) {
+    __shared__ double sm[1024];
+    const double c = center ? *center : 0.0;
+    double s = 0.0;
+    for (uint32_t i = threadIdx.x; i < P; i += 1024) {
+        const double v = d[i];
+        s += center ? (v - c) * (v - c) : v;
+    }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sm[0] / divisor;
+}
+
+__global__ void __launch_bounds__(256) reject_mask_kernel(const double *__restrict__ d, uint32_t P,
+                                                          const double *__restrict__ stat /*mean, variance*/,
+                                                          double cdf, uint8_t *__restrict__ keep) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= P) return;
+    const double tol = cdf * sqrt(stat[1]);            // Tolerance = CDF * sigma (:134)
+    keep[i] = fabs(d[i] - stat[0]) <= tol ? 1 : 0;     // (:137)
+}
+
+}  // namespace pcr
+
+using namespace pcr;
+
+extern "C" int pcr_reject_centroid_dist(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const double *pair_p,
+                                        const double *pair_q, uint32_t P, uint32_t msn, double msd, double cdf,
+                                        uint8_t *out_keep, double *out_d, double *out_stat) {
+    PCR_REQUIRE(ctx && src && tgt && out_keep, "pcr_reject_centroid_dist: NULL argument");
+    PCR_REQUIRE(src->ctx == ctx && tgt->ctx == ctx, "pcr_reject_centroid_dist: index belongs to another context");
+    PCR_REQUIRE(src->kind == tgt->kind, "pcr_reject_centroid_dist: indices must be of the same kind");
+    PCR_REQUIRE(P > 0 && pair_p && pair_q, "pcr_reject_centroid_dist: empty pair set (reference asserts, :27)");
+    PCR_REQUIRE(msn >= 1 && msn <= src->n && msn <= tgt->n, "pcr_reject_centroid_dist: MSN=%u out of range", msn);
+    if (msn > PCR_MAX_K) {
+        set_last_error("pcr_reject_centroid_dist: MSN=%u above PCR_MAX_K=%u", msn, PCR_MAX_K);
+        return PCR_E_UNSUPPORTED;
+    }
+    PCR_HIP(hipSetDevice(ctx->device));
+    double *pp_d = nullptr, *pq_d = nullptr, *d_d = nullptr;
+    uint8_t *k_d = nullptr;
+    const size_t bytes = sizeof(double) * 3 * (size_t)P;
+    hipError_t e = hipMalloc(&pp_d, bytes);
+    if (e == hipSuccess) e = hipMalloc(&pq_d, bytes);
+    if (e == hipSuccess) e = hipMalloc(&d_d, sizeof(double) * P);
+    if (e == hipSuccess) e = hipMalloc(&k_d, P);
+    if (e == hipSuccess) e = hipMemcpyAsync(pp_d, pair_p, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(pq_d, pair_q, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        const uint32_t nb = (P + 255) / 256;
+#define LAUNCH_STAT(KC)                                                                                              \
+    do {                                                                                                             \
+        if (src->kind == PCR_INDEX_GRID)                                                                             \
+            hipLaunchKernelGGL(reject_stat_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, src->view, tgt->view,    \
+                               (const double *)pp_d, (const double *)pq_d, P, (int)msn, msd, d_d);                  \
+        else                                                                                                         \
+            hipLaunchKernelGGL(reject_stat_brute_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, src->view,         \
+                               tgt->view, (const double *)pp_d, (const double *)pq_d, P, (int)msn, msd, d_d);       \
+    } while (0)
+        if (msn <= 4)
+            LAUNCH_STAT(4);
+        else if (msn <= 8)
+            LAUNCH_STAT(8);
+        else if (msn <= 16)
+            LAUNCH_STAT(16);
+        else
+            LAUNCH_STAT(32);
+#undef LAUNCH_STAT
+        double *stat_d = ctx->result_d + 20;  // [mean, variance]
+        hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const double *)d_d, P,
+                           (const double *)nullptr, (double)P, stat_d);
+        hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const double *)d_d, P,
+                           (const double *)stat_d, (double)P, stat_d + 1);
+        hipLaunchKernelGGL(reject_mask_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const double *)d_d, P,
+                           (const double *)stat_d, cdf, k_d);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(out_keep, k_d, P, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && out_d) e = hipMemcpyAsync(out_d, d_d, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(ctx->result_h + 20, stat_d, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess && out_stat) {
+            out_stat[0] = ctx->result_h[20];
+            out_stat[1] = sqrt(ctx->result_h[21]);
+        }
+    }
+    if (pp_d) hipFree(pp_d);
+    if (pq_d) hipFree(pq_d);
+    if (d_d) hipFree(d_d);
+    if (k_d) hipFree(k_d);
+    PCR_HIP(e);
+    return PCR_OK;
+}

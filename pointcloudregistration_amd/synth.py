@@ -1,0 +1,102 @@
+"""Seeded synthetic clouds for the parity tests and the benchmark.
+
+Everything is numpy `default_rng(seed)` so a fixture can be regenerated from its seed on the GPU
+box (which has no dataset and no network).  The reference's own synthetic recipe is "known rigid
+transform + uniform noise" (unit test/TestRegManDirAndClosestPoints/TestRegManDirAndClosestPoints.cpp:
+101-107); the clouds here follow it with Gaussian noise, as BASELINE.json's configs ask.
+"""
+import numpy as np
+
+
+def euler_zyx(rx_deg, ry_deg, rz_deg):
+    """R = Rz * Ry * Rx (row, col) -- the ZYX Euler matrix of unit test/TestUnitity.cpp:132-163."""
+    rx, ry, rz = np.deg2rad([rx_deg, ry_deg, rz_deg])
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def colmajor(Rm):
+    """3x3 (row, col) matrix -> the 9-vector layout of Eigen::Matrix3d::data()."""
+    return np.ascontiguousarray(np.asarray(Rm, np.float64).T).reshape(9)
+
+
+def rowcol(R9):
+    return np.asarray(R9, np.float64).reshape(3, 3).T.copy()
+
+
+_SPHERES = ((np.array([0.0, 0.0, 0.0]), 1.0), (np.array([1.3, 0.2, 0.1]), 0.6), (np.array([-0.3, 1.2, 0.4]), 0.4))
+
+
+def three_spheres(n, seed):
+    """n points, area-uniform on the union of three sphere surfaces (radii 1.0/0.6/0.4): a closed,
+    scan-like 2-D manifold in 3-D."""
+    rng = np.random.default_rng(seed)
+    area = np.array([r * r for _, r in _SPHERES])
+    which = rng.choice(len(_SPHERES), size=n, p=area / area.sum())
+    v = rng.standard_normal((n, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    c = np.stack([_SPHERES[w][0] for w in range(len(_SPHERES))])[which]
+    r = np.array([s[1] for s in _SPHERES])[which][:, None]
+    return np.ascontiguousarray(c + r * v)
+
+
+def mean_spacing(n):
+    """Typical nearest-neighbour spacing of n area-uniform points on the three-sphere surface."""
+    area = 4 * np.pi * sum(r * r for _, r in _SPHERES)
+    return float(np.sqrt(area / n))
+
+
+def registration_pair(n_src, n_tgt, seed, rot_deg=(3.0, -5.0, 8.0), trans=(0.05, -0.03, 0.02), noise=0.25):
+    """(src, tgt, R_true 3x3, t_true): tgt sampled on the surface; src = an independent sampling moved
+    by the INVERSE of the known transform plus Gaussian noise (sigma = noise * mean spacing), so that
+    R_true * src + t_true lies on the target surface."""
+    tgt = three_spheres(n_tgt, seed)
+    s = three_spheres(n_src, seed + 1)
+    rng = np.random.default_rng(seed + 2)
+    s = s + rng.standard_normal(s.shape) * (noise * mean_spacing(n_src))
+    Rm = euler_zyx(*rot_deg)
+    t = np.asarray(trans, np.float64)
+    src = (s - t) @ Rm  # = R^T (s - t), row-vector form
+    return np.ascontiguousarray(src), tgt, Rm, t
+
+
+def cube_surface(n, seed):
+    """n points uniform on the surface of the unit cube (used by the 4 096-point fixture)."""
+    rng = np.random.default_rng(seed)
+    face = rng.integers(0, 6, n)
+    uv = rng.random((n, 2))
+    p = np.empty((n, 3))
+    ax = face // 2
+    side = (face % 2).astype(np.float64)
+    for a in range(3):
+        m = ax == a
+        o = [i for i in range(3) if i != a]
+        p[m, a] = side[m]
+        p[m, o[0]] = uv[m, 0]
+        p[m, o[1]] = uv[m, 1]
+    return p
+
+
+def lidar_like(n, seed, outlier_frac=0.0, extent=(200.0, 200.0, 30.0)):
+    """LiDAR-like scene: ground plane + boxes, density falling off with range
+    from a sensor at the origin; a fraction of points replaced by uniform-in-volume outliers."""
+    rng = np.random.default_rng(seed)
+    ex, ey, ez = extent
+    # range-dependent density: r ~ sqrt(uniform) concentrates samples near the sensor
+    r = np.sqrt(rng.random(n)) * 0.5 * min(ex, ey)
+    th = rng.random(n) * 2 * np.pi
+    p = np.stack([r * np.cos(th), r * np.sin(th), np.zeros(n)], 1)
+    # a third of the points climb the walls of axis-aligned boxes on a 25 m lattice
+    wall = rng.random(n) < 0.33
+    bx = np.round(p[wall, 0] / 25.0) * 25.0
+    p[wall, 0] = bx + 4.0 * np.sign(p[wall, 0] - bx + 1e-9)
+    p[wall, 2] = rng.random(int(wall.sum())) * 0.6 * ez
+    p[:, 2] += 0.02 * np.sin(p[:, 0] * 0.3) + 0.02 * np.cos(p[:, 1] * 0.2)
+    if outlier_frac > 0:
+        m = rng.random(n) < outlier_frac
+        k = int(m.sum())
+        p[m] = (rng.random((k, 3)) - [0.5, 0.5, 0.0]) * [ex, ey, ez]
+    return np.ascontiguousarray(p)
