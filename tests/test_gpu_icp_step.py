@@ -1,0 +1,80 @@
+"""GPU parity: one ICRP iteration through the C ABI vs the golden vectors (indices produced by the
+reference's own KD-tree) and vs the oracle."""
+import numpy as np
+import pytest
+
+from conftest import case_inputs, golden
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["patch_k1", "patch_k4", "cube4096_k1", "cube4096_k4", "spheres40k_k1", "spheres40k_k4"]
+# relative tolerance on fp64 sums accumulated in a different order than the reference:
+SUM_RTOL = 1e-11
+
+
+def _indices(pcr, ctx, name, kind):
+    g = golden(name + ".npz")
+    src, tgt = case_inputs(name, g)
+    k = pcr.INDEX_GRID if kind == "grid" else pcr.INDEX_BRUTE
+    six = pcr.Index(ctx, pcr.Cloud(ctx, src), kind=k)
+    tix = pcr.Index(ctx, pcr.Cloud(ctx, tgt), kind=k)
+    return g, src, tgt, six, tix
+
+
+@pytest.mark.parametrize("kind", ["grid", "brute"])
+@pytest.mark.parametrize("name", CASES)
+def test_step_matches_golden(pcr, ctx, name, kind):
+    if kind == "brute" and name.startswith("spheres40k"):
+        pytest.skip("brute-force path is for small clouds")
+    g, src, tgt, six, tix = _indices(pcr, ctx, name, kind)
+    k = int(g["k"])
+    U = float(g["uniq_tgt"])
+    assert tix.unique_sq_dist() == U  # CUniqueData: bit-identical (same neighbours, same sum order)
+    assert six.unique_sq_dist() == float(g["uniq_src"])
+    for it in range(len(g["it_R"])):
+        R, T = g["it_R"][it], g["it_T"][it]
+        out = pcr.icp_step(ctx, six, tix, R, T, k, U * g["sdft"], U * g["ndft"], exact=True)
+        assert (out["fwd"] == g["it_fwd"][it]).all(), f"it {it}: fwd mismatches {(out['fwd'] != g['it_fwd'][it]).sum()}"
+        assert (out["rev"] == g["it_rev"][it]).all(), f"it {it}: rev mismatches {(out['rev'] != g['it_rev'][it]).sum()}"
+        assert (out["keep"] == g["it_keep"][it]).all()
+        want = g["it_partials"][it]
+        scale = np.abs(want).max()
+        assert out["partials"][0] == want[0]
+        np.testing.assert_allclose(out["partials"], want, rtol=SUM_RTOL, atol=SUM_RTOL * scale)
+        # production mode (gate early-out): identical keep mask and sums, indices only where kept
+        fast = pcr.icp_step(ctx, six, tix, R, T, k, U * g["sdft"], U * g["ndft"], exact=False)
+        assert (fast["keep"] == g["it_keep"][it]).all()
+        assert (fast["partials"] == out["partials"]).all()
+        m = fast["keep"].astype(bool)
+        assert (fast["fwd"][m] == g["it_fwd"][it][m]).all() and (fast["rev"][m] == g["it_rev"][it][m]).all()
+        # host solve: next accumulated transform = the oracle trajectory
+        pp, pq = pcr.icp_pivots(six, tix, R, T)
+        R2, T2, Rc, Tc, mse = pcr.solve_rigid(out["partials"], pp, pq, R, T)
+        np.testing.assert_allclose(R2, g["traj"][it, :9], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(T2, g["traj"][it, 9:12], rtol=0, atol=1e-9 * max(1.0, np.abs(tgt).max()))
+        np.testing.assert_allclose(mse, g["traj"][it, 12], rtol=1e-10)
+
+
+def test_sample_subset_and_order(pcr, ctx, oracle):
+    """Explicit sample lists (SamplerRandom-style subsets), in arbitrary order, with repeats."""
+    g, src, tgt, six, tix = _indices(pcr, ctx, "cube4096_k4", "grid")
+    rng = np.random.default_rng(3)
+    smp = rng.integers(0, len(src), 1500).astype(np.uint32)
+    R, T, U = g["it_R"][1], g["it_T"][1], float(g["uniq_tgt"])
+    want = oracle.icrp_correspondences(src, tgt, oracle.KdOld(tgt, 4), R, T, 4, U * 36, U * 4, sample_idx=smp)
+    out = pcr.icp_step(ctx, six, tix, R, T, 4, U * 36, U * 4, sample_idx=smp)
+    assert (out["fwd"] == want["fwd"]).all() and (out["rev"] == want["rev"]).all() and (out["keep"] == want["keep"]).all()
+    assert out["partials"][0] == want["P"]
+
+
+def test_no_pair_survives(pcr, ctx):
+    """Far-apart clouds: the reference divides by zero (RegUtilityFunctions.cpp:71); the ABI reports it."""
+    g, src, tgt, six, tix = _indices(pcr, ctx, "patch_k1", "grid")
+    R, T = np.eye(3).reshape(9), np.zeros(3)
+    U = float(g["uniq_tgt"])
+    out = pcr.icp_step(ctx, six, tix, R, T, 1, U * 36, U * 4)
+    assert out["partials"][0] == 0 and out["keep"].sum() == 0
+    pp, pq = pcr.icp_pivots(six, tix, R, T)
+    with pytest.raises(pcr.PcrError) as e:
+        pcr.solve_rigid(out["partials"], pp, pq, R, T)
+    assert e.value.status == -5
