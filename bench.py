@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- ICP iterations/s (and KNN queries/s) of the MI355X hot path on BASELINE.json's headline
+workload: synthetic 1M x 1M-point clouds, known rigid transform + Gaussian noise, K = NN = 4,
+SDFT = 36, NDFT = 4, every source point a sample.
+
+One "step" = ONE ICRP iteration: transform the source, forward K-NN, reverse 1-NN, both gates, the
+17-sum reduction (+ all-reduce over ranks), host 3x3 SVD + composition.  Inputs and indices are
+resident in HBM before the timed region; index builds are reported separately.
+
+  python bench.py --gpus 1 --steps 30 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+For N > 1 the samples are sharded over the ranks at FIXED problem size (strong scaling), clouds and
+indices replicated, partials combined by an RCCL all-reduce (torch.distributed backend "nccl").
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 20250001
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_sample(k):
+    """read s_i (24) + K forward winners (24K) + reverse winner (24) + two u32 out (8)."""
+    return 56 + 24 * k
+
+
+def cpu_baseline(src, tgt, R0, T0, k, sdft, ndft, budget_s=25.0):
+    """The oracle (CPU restatement of the reference loop) timed on this box's host cores -- the CHECKER
+    timed as a baseline, never the thing measured above.  Per iteration it does what the reference does:
+    copy + transform the source, rebuild the source KD-tree, serial forward K-NN + reverse 1-NN per
+    sample, two-pass centroid/covariance + SVD (the target tree is built once, outside, like the
+    reference's __setMethodPointCloud)."""
+    from oracle import oracle as O
+    U = O.uniq_sq_dist(tgt)
+    t0 = time.perf_counter()
+    ttree = O.KdOld(tgt, k)
+    build_s = time.perf_counter() - t0
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+
+    def run(threads, iters):
+        R, T = np.array(R0, np.float64), np.array(T0, np.float64)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            c = O.icrp_correspondences(src, tgt, ttree, R, T, k, U * sdft, U * ndft, threads=threads)
+            R, T, _, _ = O.svd2(c["pair_p"], c["pair_q"], R, T)
+        return (time.perf_counter() - t0) / iters
+
+    s_multi = run(cores, 2)
+    iters_single = 2 if s_multi * cores * 0.6 * 2 < budget_s else 1
+    s_single = run(1, iters_single)
+    return {"value": 1.0 / s_multi, "unit": "iterations/s", "cores": cores, "kind": "port",
+            "sample": f"2 full ICRP iterations at {len(src)}x{len(tgt)} points, K={k}, OpenMP over samples on "
+                      f"{cores} threads (source KD-tree rebuilt serially every iteration, as the reference does); "
+                      f"target-tree build {build_s:.2f} s excluded",
+            "single_thread_value": 1.0 / s_single, "single_thread_iterations": iters_single,
+            "seconds_per_iteration": s_multi, "single_thread_seconds_per_iteration": s_single}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=1_000_000, help="points per cloud (headline: 1M)")
+    ap.add_argument("--k", type=int, default=4, help="CorrespondenceEstimationClosestPoints.NN")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-knn", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pointcloudregistration_amd import capi, synth
+    from pointcloudregistration_amd.dist import shard_range
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node = --gpus"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    n, k, sdft, ndft = args.points, args.k, 36.0, 4.0
+    src, tgt, R_true, t_true = synth.registration_pair(n, n, SEED)
+
+    stream = torch.cuda.current_stream()
+    ctx = capi.Context(local_rank, stream=stream)
+    src_t = torch.from_numpy(src).to(dev)
+    tgt_t = torch.from_numpy(tgt).to(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    scloud, tcloud = capi.Cloud(ctx, src_t), capi.Cloud(ctx, tgt_t)
+    six, tix = capi.Index(ctx, scloud, kind=capi.INDEX_GRID), capi.Index(ctx, tcloud, kind=capi.INDEX_GRID)
+    ctx.synchronize()
+    build_ms = (time.perf_counter() - t0) * 1e3
+    U = tix.unique_sq_dist()
+    thr_f, thr_r = U * sdft, U * ndft
+
+    begin, m = shard_range(n, rank, world)
+    part_t = torch.zeros(17, dtype=torch.float64, device=dev)
+    R0, T0 = synth.coarse_initial_transform(R_true, t_true, n)
+
+    def iteration(R, T):
+        capi.icp_step_d(ctx, six, tix, R, T, k, thr_f, thr_r, part_t, sample_begin=begin, m=m)
+        if world > 1:
+            dist.all_reduce(part_t)
+        p = part_t.cpu().numpy()  # synchronises the stream: the dependent chain of a real fit
+        pp, pq = capi.icp_pivots(six, tix, R, T)
+        R2, T2, _, _, mse = capi.solve_rigid(p, pp, pq, R, T)
+        return R2, T2, mse, p[0]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    R, T = R0.copy(), T0.copy()
+    for _ in range(args.warmup):
+        R, T, mse, kept = iteration(R, T)
+    # the timed fit restarts from the coarse initial transform: steps 1..K of one registration
+    R, T = R0.copy(), T0.copy()
+    ctx.set_profiling(True)
+    ctx.read_kernel_times()  # reset
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        R, T, mse, kept = iteration(R, T)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kt = ctx.read_kernel_times()
+    ctx.set_profiling(False)
+    if world > 1:
+        et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+        elapsed = float(et.item())
+
+    # registration quality of the timed fit (not part of the metric; shows the work was real)
+    R_est = synth.rowcol(R)
+    rot_err = float(np.abs(R_est - R_true).max())
+    trans_err = float(np.abs(T - t_true).max())
+
+    knn = None
+    if rank == 0 and not args.no_knn:
+        q_t = torch.from_numpy(np.ascontiguousarray(src @ R_true.T + t_true)).to(dev)
+        knn = {}
+        for kk in (1, 4):
+            oi = torch.empty((n, kk), dtype=torch.int32, device=dev)
+            ts = []
+            for rep in range(6):
+                torch.cuda.synchronize()
+                a = time.perf_counter()
+                tix.knn_d(q_t, kk, oi)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - a)
+            knn[f"k{kk}"] = n / float(np.median(ts[1:]))
+
+    if rank == 0:
+        step_ms = kt["step"][0] / max(1, kt["step"][1])
+        algo_bytes = algorithmic_bytes_per_sample(k) * m
+        achieved = algo_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
+        info = tix.info()
+        out = {
+            "metric": "icp_iterations_per_s", "value": args.steps / elapsed, "unit": "iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"C3 synthetic {n}x{n}-point three-sphere surface, known rigid transform + "
+                                   f"Gaussian noise (seed {SEED}), K={k}, SDFT={sdft:g}, NDFT={ndft:g}, every "
+                                   f"source point a sample, {args.steps} ICRP iterations from a coarse alignment "
+                                   f"(known transform perturbed by ~1.5 point spacings)",
+                       "points_per_cloud": n, "k": k, "parallelism": f"sample-sharded x{world}, clouds+indices "
+                       "replicated, 17-double all-reduce per iteration"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": f"icp_step_grid_kernel<{k if k in (1, 4, 8, 16, 32) else '>=k'}>",
+                         "kernel_ms_avg": step_ms, "launches": kt["step"][1],
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "other_kernels_ms_avg": {"transform": kt["transform"][0] / max(1, kt["transform"][1]),
+                                                  "fold": kt["fold"][0] / max(1, kt["fold"][1])}},
+            "knn_queries_per_s": knn,
+            "index": {"build_ms_both_clouds": build_ms, "cell_size": info["cell_size"], "dims": info["dims"],
+                      "mean_occupancy": info["mean_occupancy"], "cells": info["cells"]},
+            "fit": {"kept_pairs_last": float(kept), "mse_last": float(mse), "max_abs_rot_err": rot_err,
+                    "max_abs_trans_err": trans_err},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(src, tgt, R0, T0, k, sdft, ndft)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

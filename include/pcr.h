@@ -59,11 +59,22 @@ const char *pcr_version(void);
 
 /* ---- context -----------------------------------------------------------------------
  * No reference counterpart (the reference is single-threaded CPU code).  One context =
- * one device + one HIP stream + reusable scratch.  stream may be NULL (the context then
- * creates its own) or an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
-int pcr_ctx_create(int device, void *hip_stream, pcr_ctx **out);
+ * one device + one HIP stream + reusable scratch.  A new context owns a private non-blocking
+ * stream; pcr_ctx_set_stream makes it enqueue on a caller's hipStream_t instead (for example
+ * torch.cuda.current_stream().cuda_stream; NULL selects the legacy default stream), so that
+ * _d entry points are ordered with the caller's own work on that stream. */
+int pcr_ctx_create(int device, pcr_ctx **out);
+int pcr_ctx_set_stream(pcr_ctx *ctx, void *hip_stream);
 int pcr_ctx_destroy(pcr_ctx *ctx);
 int pcr_ctx_synchronize(pcr_ctx *ctx);
+/* Optional measurement hooks (no reference counterpart; the reference times whole fits with
+ * GetTickCount, unit test/FineRegistration/TestFineRegistration.cpp:50-68).  When on, every kernel
+ * launch of the classes below is bracketed by a HIP event pair on the context's stream.
+ * pcr_ctx_read_kernel_times synchronises, returns per class the summed kernel time in ms and the
+ * number of launches since the previous read, and resets the counters.
+ * class 0: source transform, 1: fused ICP step, 2: partial fold, 3: K-NN query. */
+int pcr_ctx_set_profiling(pcr_ctx *ctx, int on);
+int pcr_ctx_read_kernel_times(pcr_ctx *ctx, double sum_ms[4], uint32_t launches[4]);
 
 /* ---- clouds ------------------------------------------------------------------------
  * Replaces the borrowed `const double*` of hiveCommon::CKNNSearch::initKNNSearch

@@ -48,7 +48,10 @@ SYMBOLS = {
     "pcr_strerror": (C.c_char_p, [C.c_int]),
     "pcr_last_error": (C.c_char_p, []),
     "pcr_version": (C.c_char_p, []),
-    "pcr_ctx_create": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
+    "pcr_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "pcr_ctx_set_stream": (C.c_int, [_vp, _vp]),
+    "pcr_ctx_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "pcr_ctx_read_kernel_times": (C.c_int, [_vp, _dp, _up]),
     "pcr_ctx_destroy": (C.c_int, [_vp]),
     "pcr_ctx_synchronize": (C.c_int, [_vp]),
     "pcr_cloud_upload": (C.c_int, [_vp, _dp, C.c_uint32, C.POINTER(_vp)]),
@@ -120,13 +123,25 @@ def _rt(R, T):
 
 
 class Context:
-    """pcr_ctx: one device + one stream.  stream: None (own stream) or a torch.cuda.Stream."""
+    """pcr_ctx: one device + one stream.  stream: None (the context's own stream) or a torch.cuda.Stream
+    (the default stream included) on which the _d entry points are then ordered."""
 
     def __init__(self, device=0, stream=None):
         self.h = _vp()
-        sp = _vp(stream.cuda_stream) if stream is not None else None
-        _check(lib().pcr_ctx_create(device, sp, C.byref(self.h)), "pcr_ctx_create")
+        _check(lib().pcr_ctx_create(device, C.byref(self.h)), "pcr_ctx_create")
         self.device = device
+        if stream is not None:
+            _check(lib().pcr_ctx_set_stream(self.h, _vp(stream.cuda_stream)), "pcr_ctx_set_stream")
+
+    def set_profiling(self, on):
+        _check(lib().pcr_ctx_set_profiling(self.h, 1 if on else 0), "pcr_ctx_set_profiling")
+
+    def read_kernel_times(self):
+        """{class: (sum_ms, launches)} since the previous read; synchronises the stream."""
+        ms = np.zeros(4)
+        cnt = np.zeros(4, np.uint32)
+        _check(lib().pcr_ctx_read_kernel_times(self.h, _d(ms), _u(cnt)), "pcr_ctx_read_kernel_times")
+        return {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(("transform", "step", "fold", "knn"))}
 
     def synchronize(self):
         _check(lib().pcr_ctx_synchronize(self.h), "pcr_ctx_synchronize")

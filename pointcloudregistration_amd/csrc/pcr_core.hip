@@ -272,7 +272,7 @@ const char *pcr_last_error(void) { return g_last_error; }
 
 const char *pcr_version(void) { return "libpcr 0.1 (gfx950, fp64, -ffp-contract=off)"; }
 
-int pcr_ctx_create(int device, void *hip_stream, pcr_ctx **out) {
+int pcr_ctx_create(int device, pcr_ctx **out) {
     PCR_REQUIRE(out, "pcr_ctx_create: out is NULL");
     *out = nullptr;
     int count = 0;
@@ -291,13 +291,15 @@ int pcr_ctx_create(int device, void *hip_stream, pcr_ctx **out) {
     }
     pcr_ctx *c = new pcr_ctx();
     c->device = device;
-    c->own_stream = hip_stream == nullptr;
-    c->stream = (hipStream_t)hip_stream;
+    c->profiling = false;
+    c->prof = nullptr;
+    c->own_stream = true;
+    c->stream = nullptr;
     c->block_partials_d = nullptr;
     c->block_partials_cap = 0;
     c->result_d = nullptr;
     c->result_h = nullptr;
-    if (c->own_stream) {
+    {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e != hipSuccess) {
             delete c;
@@ -321,8 +323,57 @@ int pcr_ctx_destroy(pcr_ctx *c) {
     if (c->block_partials_d) hipFree(c->block_partials_d);
     if (c->result_d) hipFree(c->result_d);
     if (c->result_h) hipHostFree(c->result_h);
+    if (c->prof) {
+        for (int k = 0; k < PCR_PROF_CLASSES; ++k)
+            for (int i = 0; i < c->prof->created[k]; ++i) {
+                hipEventDestroy(c->prof->start[k][i]);
+                hipEventDestroy(c->prof->stop[k][i]);
+            }
+        delete c->prof;
+    }
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
+    return PCR_OK;
+}
+
+int pcr_ctx_set_profiling(pcr_ctx *c, int on) {
+    PCR_REQUIRE(c, "pcr_ctx_set_profiling: ctx is NULL");
+    if (on && !c->prof) {
+        c->prof = new pcr_prof();
+        memset(c->prof, 0, sizeof(pcr_prof));
+    }
+    c->profiling = on != 0;
+    return PCR_OK;
+}
+
+int pcr_ctx_read_kernel_times(pcr_ctx *c, double sum_ms[4], uint32_t launches[4]) {
+    PCR_REQUIRE(c && sum_ms && launches, "pcr_ctx_read_kernel_times: NULL argument");
+    for (int k = 0; k < PCR_PROF_CLASSES; ++k) {
+        sum_ms[k] = 0;
+        launches[k] = 0;
+    }
+    if (!c->prof) return PCR_OK;
+    PCR_HIP(hipSetDevice(c->device));
+    PCR_HIP(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < PCR_PROF_CLASSES; ++k) {
+        for (int i = 0; i < c->prof->used[k]; ++i) {
+            float ms = 0;
+            PCR_HIP(hipEventElapsedTime(&ms, c->prof->start[k][i], c->prof->stop[k][i]));
+            sum_ms[k] += ms;
+        }
+        launches[k] = (uint32_t)c->prof->used[k];
+        c->prof->used[k] = 0;
+    }
+    return PCR_OK;
+}
+
+int pcr_ctx_set_stream(pcr_ctx *c, void *hip_stream) {
+    PCR_REQUIRE(c, "pcr_ctx_set_stream: ctx is NULL");
+    PCR_HIP(hipSetDevice(c->device));
+    PCR_HIP(hipStreamSynchronize(c->stream));  // nothing of ours may still be in flight on the old stream
+    if (c->own_stream && c->stream) PCR_HIP(hipStreamDestroy(c->stream));
+    c->own_stream = false;
+    c->stream = (hipStream_t)hip_stream;
     return PCR_OK;
 }
 

@@ -368,8 +368,11 @@ int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
     A.block_partials = ctx->block_partials_d;
 
     // CPointCloud::transform of the whole source (:73-74), in index order
-    hipLaunchKernelGGL(transform_kernel, dim3(min(2048u, (src->n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const Pt4 *)src->pts_d, src->n, A.M, src->tpts_d);
+    {
+        ProfScope ps(ctx, PCR_PROF_TRANSFORM);
+        hipLaunchKernelGGL(transform_kernel, dim3(min(2048u, (src->n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const Pt4 *)src->pts_d, src->n, A.M, src->tpts_d);
+    }
 #define LAUNCH_STEP(KC)                                                                                           \
     do {                                                                                                          \
         if (src->kind == PCR_INDEX_GRID)                                                                          \
@@ -377,19 +380,25 @@ int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
         else                                                                                                      \
             hipLaunchKernelGGL(icp_step_brute_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, A);                \
     } while (0)
-    if (k == 1)
-        LAUNCH_STEP(1);
-    else if (k <= 4)
-        LAUNCH_STEP(4);
-    else if (k <= 8)
-        LAUNCH_STEP(8);
-    else if (k <= 16)
-        LAUNCH_STEP(16);
-    else
-        LAUNCH_STEP(32);
+    {
+        ProfScope ps(ctx, PCR_PROF_STEP);
+        if (k == 1)
+            LAUNCH_STEP(1);
+        else if (k <= 4)
+            LAUNCH_STEP(4);
+        else if (k <= 8)
+            LAUNCH_STEP(8);
+        else if (k <= 16)
+            LAUNCH_STEP(16);
+        else
+            LAUNCH_STEP(32);
+    }
 #undef LAUNCH_STEP
-    hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double *)ctx->block_partials_d,
-                       nb, partials_d);
+    {
+        ProfScope ps(ctx, PCR_PROF_FOLD);
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, ctx->stream,
+                           (const double *)ctx->block_partials_d, nb, partials_d);
+    }
     PCR_HIP(hipGetLastError());
     return PCR_OK;
 }

@@ -49,8 +49,21 @@ struct GridView {
 
 }  // namespace pcr
 
+// kernel classes timed by the optional profiling hooks (pcr_ctx_set_profiling)
+enum { PCR_PROF_TRANSFORM = 0, PCR_PROF_STEP = 1, PCR_PROF_FOLD = 2, PCR_PROF_KNN = 3, PCR_PROF_CLASSES = 4 };
+constexpr int PCR_PROF_CAP = 1024;  // launches recorded per class between two reads
+
+struct pcr_prof {
+    hipEvent_t start[PCR_PROF_CLASSES][PCR_PROF_CAP];
+    hipEvent_t stop[PCR_PROF_CLASSES][PCR_PROF_CAP];
+    int created[PCR_PROF_CLASSES];
+    int used[PCR_PROF_CLASSES];
+};
+
 struct pcr_ctx {
     int device;
+    bool profiling;
+    pcr_prof *prof;
     hipStream_t stream;
     bool own_stream;
     // reusable device scratch for block partials of the fused step (grown on demand, never per call
@@ -60,6 +73,29 @@ struct pcr_ctx {
     double *result_d;           // [32] device
     double *result_h;           // [32] pinned host
 };
+
+namespace pcr {
+// RAII bracket: records a start/stop event pair around a launch when profiling is on.
+struct ProfScope {
+    pcr_ctx *c;
+    int cls, slot;
+    ProfScope(pcr_ctx *ctx, int k) : c(ctx), cls(k), slot(-1) {
+        if (!c->profiling || !c->prof) return;
+        pcr_prof &p = *c->prof;
+        if (p.used[cls] >= PCR_PROF_CAP) return;
+        if (p.used[cls] >= p.created[cls]) {
+            if (hipEventCreate(&p.start[cls][p.created[cls]]) != hipSuccess) return;
+            if (hipEventCreate(&p.stop[cls][p.created[cls]]) != hipSuccess) return;
+            ++p.created[cls];
+        }
+        slot = p.used[cls]++;
+        (void)hipEventRecord(p.start[cls][slot], c->stream);
+    }
+    ~ProfScope() {
+        if (slot >= 0) (void)hipEventRecord(c->prof->stop[cls][slot], c->stream);
+    }
+};
+}  // namespace pcr
 
 struct pcr_cloud {
     pcr_ctx *ctx;

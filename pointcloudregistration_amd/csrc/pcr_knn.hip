@@ -107,6 +107,7 @@ int pcr_knn_d(pcr_ctx *ctx, const pcr_index *ix, const double *q_d, uint32_t nq,
     PCR_REQUIRE(q_d, "pcr_knn_d: q_d is NULL");
     PCR_HIP(hipSetDevice(ctx->device));
     if (!(max_d2 >= 0) || isinf(max_d2)) max_d2 = PCR_INF_H;  // negative / NaN / inf: unbounded
+    ProfScope ps(ctx, PCR_PROF_KNN);
     if (k == 1)
         launch_knn<1>(ctx, ix, q_d, nq, k, order, max_d2, out_idx_d, out_d2_d);
     else if (k <= 4)

@@ -100,3 +100,17 @@ def lidar_like(n, seed, outlier_frac=0.0, extent=(200.0, 200.0, 30.0)):
         k = int(m.sum())
         p[m] = (rng.random((k, 3)) - [0.5, 0.5, 0.0]) * [ex, ey, ez]
     return np.ascontiguousarray(p)
+
+
+def coarse_initial_transform(R_true, t_true, n, rot_spacings=1.5, trans_spacings=1.0):
+    """(R0 col-major 9, T0): the known transform composed with a small rigid perturbation, sized in units of
+    the cloud's mean point spacing.  ICRP is a FINE registration: its gates are a few spacings wide
+    (sqrt(36 U)), so -- as in the reference, where coarseFit precedes fineFit (Registration.cpp:120-158) --
+    the loop is started from a coarse alignment, not from the identity."""
+    h = mean_spacing(n)
+    ang = np.rad2deg(rot_spacings * h / 1.0)  # displacement of ~rot_spacings*h at unit radius
+    dR = euler_zyx(0.3 * ang, -0.5 * ang, 0.8 * ang)
+    dt = np.array([0.6, -0.5, 0.4]) * trans_spacings * h
+    R0 = dR @ R_true
+    T0 = dR @ t_true + dt
+    return colmajor(R0), T0
