@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=1_000_000, help="points per cloud (headline: 1M)")
     ap.add_argument("--k", type=int, default=4, help="CorrespondenceEstimationClosestPoints.NN")
+    ap.add_argument("--occupancy", type=float, default=0.0, help="grid target occupancy (0 = library default)")
+    ap.add_argument("--tune", type=str, default="", help="debug: comma list key=value for pcr_tune")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-knn", action="store_true")
     args = ap.parse_args()
@@ -97,6 +99,9 @@ def main():
     n, k, sdft, ndft = args.points, args.k, 36.0, 4.0
     src, tgt, R_true, t_true = synth.registration_pair(n, n, SEED)
 
+    for kv in filter(None, args.tune.split(",")):
+        kk, vv = kv.split("=")
+        capi.lib().pcr_tune(int(kk), int(vv))
     stream = torch.cuda.current_stream()
     ctx = capi.Context(local_rank, stream=stream)
     src_t = torch.from_numpy(src).to(dev)
@@ -104,7 +109,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     scloud, tcloud = capi.Cloud(ctx, src_t), capi.Cloud(ctx, tgt_t)
-    six, tix = capi.Index(ctx, scloud, kind=capi.INDEX_GRID), capi.Index(ctx, tcloud, kind=capi.INDEX_GRID)
+    six = capi.Index(ctx, scloud, kind=capi.INDEX_GRID, target_occupancy=args.occupancy)
+    tix = capi.Index(ctx, tcloud, kind=capi.INDEX_GRID, target_occupancy=args.occupancy)
     ctx.synchronize()
     build_ms = (time.perf_counter() - t0) * 1e3
     U = tix.unique_sq_dist()

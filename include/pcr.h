@@ -56,6 +56,9 @@ const char *pcr_strerror(int status);
 const char *pcr_last_error(void);
 /* library version string; also names the target ISA it was compiled for */
 const char *pcr_version(void);
+/* Tuning knobs for experiments (no reference counterpart).  key 0: 0 = wave-cooperative search (default),
+ * 1 = one lane per query; key 1: initial halo (cells) of the wave box.  Results do not depend on them. */
+int pcr_tune(int key, int value);
 
 /* ---- context -----------------------------------------------------------------------
  * No reference counterpart (the reference is single-threaded CPU code).  One context =

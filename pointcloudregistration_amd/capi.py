@@ -48,6 +48,7 @@ SYMBOLS = {
     "pcr_strerror": (C.c_char_p, [C.c_int]),
     "pcr_last_error": (C.c_char_p, []),
     "pcr_version": (C.c_char_p, []),
+    "pcr_tune": (C.c_int, [C.c_int, C.c_int]),
     "pcr_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "pcr_ctx_set_stream": (C.c_int, [_vp, _vp]),
     "pcr_ctx_set_profiling": (C.c_int, [_vp, C.c_int]),

@@ -101,6 +101,48 @@ __device__ __forceinline__ int cell_coord(double v, double lo, double inv_h, int
     return (int)t;
 }
 
+// Squared lower bound on the distance from the grid-frame query s to every point whose cell lies
+// OUTSIDE the cell box [x0..x1]x[y0..y1]x[z0..z1] (faces on the grid boundary have nothing beyond
+// them).  Conservative against rounding: each face gap is shrunk by `margin`; o?2 are the squared
+// per-axis distances of s to the bounds of the points (0 inside), already shrunk the same way.
+__device__ __forceinline__ double box_bound2(const GridView &g, double sx, double sy, double sz, double margin,
+                                             double ox2, double oy2, double oz2, int x0, int x1, int y0, int y1,
+                                             int z0, int z1) {
+    double b2 = PCR_INF;
+    const double o_yz = oy2 + oz2, o_xz = ox2 + oz2, o_xy = ox2 + oy2;
+    if (x0 > 0) {
+        double gap = sx - (g.lo[0] + (double)x0 * g.h) - margin;
+        gap = gap > 0.0 ? gap : 0.0;
+        b2 = fmin(b2, gap * gap + o_yz);
+    }
+    if (x1 < g.g[0] - 1) {
+        double gap = (g.lo[0] + (double)(x1 + 1) * g.h) - sx - margin;
+        gap = gap > 0.0 ? gap : 0.0;
+        b2 = fmin(b2, gap * gap + o_yz);
+    }
+    if (y0 > 0) {
+        double gap = sy - (g.lo[1] + (double)y0 * g.h) - margin;
+        gap = gap > 0.0 ? gap : 0.0;
+        b2 = fmin(b2, gap * gap + o_xz);
+    }
+    if (y1 < g.g[1] - 1) {
+        double gap = (g.lo[1] + (double)(y1 + 1) * g.h) - sy - margin;
+        gap = gap > 0.0 ? gap : 0.0;
+        b2 = fmin(b2, gap * gap + o_xz);
+    }
+    if (z0 > 0) {
+        double gap = sz - (g.lo[2] + (double)z0 * g.h) - margin;
+        gap = gap > 0.0 ? gap : 0.0;
+        b2 = fmin(b2, gap * gap + o_xy);
+    }
+    if (z1 < g.g[2] - 1) {
+        double gap = (g.lo[2] + (double)(z1 + 1) * g.h) - sz - margin;
+        gap = gap > 0.0 ? gap : 0.0;
+        b2 = fmin(b2, gap * gap + o_xy);
+    }
+    return b2;
+}
+
 // Exact K-NN of one query on the grid.
 //   cand     : candidate coordinates, parallel to g.pts (g.pts itself for a plain search, the
 //              transformed copy for the reverse search of the ICP step)
@@ -196,40 +238,7 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
         // ---- can anything outside the scanned box still matter? ----
         const bool all = (x0 == 0) & (x1 == gx - 1) & (y0 == 0) & (y1 == gy - 1) & (z0 == 0) & (z1 == gz - 1);
         if (all) break;
-        double b2 = PCR_INF;
-        {
-            const double o_yz = oy2 + oz2, o_xz = ox2 + oz2, o_xy = ox2 + oy2;
-            if (x0 > 0) {
-                double gap = sx - (g.lo[0] + (double)x0 * g.h) - margin;
-                gap = gap > 0.0 ? gap : 0.0;
-                b2 = fmin(b2, gap * gap + o_yz);
-            }
-            if (x1 < gx - 1) {
-                double gap = (g.lo[0] + (double)(x1 + 1) * g.h) - sx - margin;
-                gap = gap > 0.0 ? gap : 0.0;
-                b2 = fmin(b2, gap * gap + o_yz);
-            }
-            if (y0 > 0) {
-                double gap = sy - (g.lo[1] + (double)y0 * g.h) - margin;
-                gap = gap > 0.0 ? gap : 0.0;
-                b2 = fmin(b2, gap * gap + o_xz);
-            }
-            if (y1 < gy - 1) {
-                double gap = (g.lo[1] + (double)(y1 + 1) * g.h) - sy - margin;
-                gap = gap > 0.0 ? gap : 0.0;
-                b2 = fmin(b2, gap * gap + o_xz);
-            }
-            if (z0 > 0) {
-                double gap = sz - (g.lo[2] + (double)z0 * g.h) - margin;
-                gap = gap > 0.0 ? gap : 0.0;
-                b2 = fmin(b2, gap * gap + o_xy);
-            }
-            if (z1 < gz - 1) {
-                double gap = (g.lo[2] + (double)(z1 + 1) * g.h) - sz - margin;
-                gap = gap > 0.0 ? gap : 0.0;
-                b2 = fmin(b2, gap * gap + o_xy);
-            }
-        }
+        double b2 = box_bound2(g, sx, sy, sz, margin, ox2, oy2, oz2, x0, x1, y0, y1, z0, z1);
         b2 *= bound_scale;
         // strict: an unvisited point at exactly the K-th distance could still win on index
         if (wd < b2 || max_d2 <= b2) break;

@@ -13,6 +13,7 @@
 namespace pcr {
 
 static thread_local char g_last_error[512] = "";
+int g_tune[8] = {0, 1, 0, 0, 0, 0, 0, 0};
 
 void set_last_error(const char *fmt, ...) {
     va_list ap;
@@ -220,6 +221,110 @@ __global__ void __launch_bounds__(256) pack_kernel(const double *__restrict__ xy
     }
 }
 
+// ------------------------------------------------------------------ brick ordering of queries
+struct BrickGeom {
+    GridGeom G;
+    int shift;  // brick edge = 2^shift cells
+    int bits;   // Morton bits per axis
+};
+
+// spread the low 10 bits of v so that there are two zero bits between consecutive bits
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__device__ __forceinline__ uint32_t brick_of(const BrickGeom &B, double x, double y, double z) {
+    double tx = (x - B.G.lo[0]) * B.G.inv_h, ty = (y - B.G.lo[1]) * B.G.inv_h, tz = (z - B.G.lo[2]) * B.G.inv_h;
+    // non-finite coordinates land in brick 0 (their lanes are masked later)
+    tx = tx > 0.0 ? tx : 0.0;
+    ty = ty > 0.0 ? ty : 0.0;
+    tz = tz > 0.0 ? tz : 0.0;
+    const double mx = (double)(B.G.g[0] - 1), my = (double)(B.G.g[1] - 1), mz = (double)(B.G.g[2] - 1);
+    tx = tx > mx ? mx : tx;
+    ty = ty > my ? my : ty;
+    tz = tz > mz ? mz : tz;
+    const int bx = (int)tx >> B.shift, by = (int)ty >> B.shift, bz = (int)tz >> B.shift;
+    // Morton (Z-order) key: consecutive keys are neighbours in space, so 64 consecutive queries share a
+    // compact box
+    return spread3((uint32_t)bx) | (spread3((uint32_t)by) << 1) | (spread3((uint32_t)bz) << 2);
+}
+
+__device__ __forceinline__ void load_xyz(const Pt4 *pts, const double *aos, uint32_t i, double &x, double &y,
+                                         double &z) {
+    if (pts) {
+        const Pt4 p = pts[i];
+        x = p.x;
+        y = p.y;
+        z = p.z;
+    } else {
+        x = aos[(size_t)i * 3];
+        y = aos[(size_t)i * 3 + 1];
+        z = aos[(size_t)i * 3 + 2];
+    }
+}
+
+__global__ void __launch_bounds__(256) brick_histogram_kernel(const Pt4 *__restrict__ pts,
+                                                              const double *__restrict__ aos, uint32_t n, BrickGeom B,
+                                                              uint32_t *__restrict__ counts,
+                                                              uint32_t *__restrict__ brick_id) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double x, y, z;
+        load_xyz(pts, aos, i, x, y, z);
+        const uint32_t b = brick_of(B, x, y, z);
+        brick_id[i] = b;
+        atomicAdd(&counts[b], 1u);
+    }
+}
+
+__global__ void __launch_bounds__(256) brick_scatter_kernel(const uint32_t *__restrict__ brick_id, uint32_t n,
+                                                            uint32_t *__restrict__ cursor,
+                                                            uint32_t *__restrict__ order) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        order[atomicAdd(&cursor[brick_id[i]], 1u)] = i;
+}
+
+// after the scatter cursor[b] == end of brick b; start = end of the previous brick
+__global__ void __launch_bounds__(256) brick_sort_kernel(const uint32_t *__restrict__ ends, uint32_t nbricks,
+                                                         uint32_t *__restrict__ order) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbricks) return;
+    const uint32_t beg = b ? ends[b - 1] : 0u, end = ends[b];
+    if (end - beg < 2 || end - beg > 2048) return;
+    for (uint32_t i = beg + 1; i < end; ++i) {
+        const uint32_t v = order[i];
+        uint32_t j = i;
+        while (j > beg && order[j - 1] > v) {
+            order[j] = order[j - 1];
+            --j;
+        }
+        order[j] = v;
+    }
+}
+
+void *ctx_scratch(pcr_ctx *ctx, int slot, size_t bytes) {
+    if (bytes <= ctx->scratch_cap[slot] && ctx->scratch_d[slot]) return ctx->scratch_d[slot];
+    if (ctx->scratch_d[slot]) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(ctx->scratch_d[slot]);
+        ctx->scratch_d[slot] = nullptr;
+        ctx->scratch_cap[slot] = 0;
+    }
+    const size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&ctx->scratch_d[slot], want);
+    if (e != hipSuccess) {
+        set_last_error("scratch allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+        ctx->scratch_d[slot] = nullptr;
+        return nullptr;
+    }
+    ctx->scratch_cap[slot] = want;
+    return ctx->scratch_d[slot];
+}
+
 static int grid_blocks(uint64_t work, int block = 256, int cap = 2048) {
     uint64_t b = (work + block - 1) / block;
     if (b < 1) b = 1;
@@ -249,6 +354,49 @@ static int compute_bounds(pcr_ctx *ctx, const double *xyz_d, uint32_t n, double 
     return PCR_OK;
 }
 
+
+int brick_order(pcr_ctx *ctx, const GridView &g, const Pt4 *pts, const double *xyz_aos, uint32_t n,
+                uint32_t *order_d, bool deterministic) {
+    BrickGeom B;
+    for (int a = 0; a < 3; ++a) {
+        B.G.lo[a] = g.lo[a];
+        B.G.g[a] = g.g[a];
+    }
+    B.G.inv_h = g.inv_h;
+    B.shift = 2;
+    uint64_t nbricks;
+    for (;;) {  // Morton key space 2^(3*bits) <= 2^24 entries: grow the brick until 8 bits per axis suffice
+        int maxnb = 1;
+        for (int a = 0; a < 3; ++a) maxnb = maxnb > ((g.g[a] - 1) >> B.shift) + 1 ? maxnb : ((g.g[a] - 1) >> B.shift) + 1;
+        B.bits = 1;
+        while ((1 << B.bits) < maxnb) ++B.bits;
+        if (B.bits <= 8) break;
+        ++B.shift;
+    }
+    nbricks = 1ull << (3 * B.bits);
+    const uint32_t tiles = (uint32_t)((nbricks + SCAN_TILE - 1) / SCAN_TILE);
+    uint32_t *counts = (uint32_t *)ctx_scratch(ctx, 0, sizeof(uint32_t) * (nbricks + 1));
+    uint32_t *tile_sums = (uint32_t *)ctx_scratch(ctx, 1, sizeof(uint32_t) * (tiles + 1));
+    uint32_t *brick_id = (uint32_t *)ctx_scratch(ctx, 2, sizeof(uint32_t) * (size_t)n);
+    unsigned long long *stats = (unsigned long long *)ctx_scratch(ctx, 3, 64);
+    if (!counts || !tile_sums || !brick_id || !stats) return PCR_E_NOMEM;
+    PCR_HIP(hipMemsetAsync(counts, 0, sizeof(uint32_t) * (nbricks + 1), ctx->stream));
+    PCR_HIP(hipMemsetAsync(stats, 0, 16, ctx->stream));
+    hipLaunchKernelGGL(brick_histogram_kernel, dim3(grid_blocks(n)), dim3(256), 0, ctx->stream, pts, xyz_aos, n, B,
+                       counts, brick_id);
+    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(tiles), dim3(256), 0, ctx->stream, counts, nbricks, tile_sums,
+                       stats);
+    hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, tile_sums, tiles);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(tiles), dim3(256), 0, ctx->stream, counts, nbricks, tile_sums, n);
+    hipLaunchKernelGGL(brick_scatter_kernel, dim3(grid_blocks(n)), dim3(256), 0, ctx->stream, brick_id, n, counts,
+                       order_d);
+    if (deterministic)
+        hipLaunchKernelGGL(brick_sort_kernel, dim3((unsigned)((nbricks + 255) / 256)), dim3(256), 0, ctx->stream,
+                           counts, (uint32_t)nbricks, order_d);
+    PCR_HIP(hipGetLastError());
+    return PCR_OK;
+}
+
 }  // namespace pcr
 
 using namespace pcr;
@@ -269,6 +417,12 @@ const char *pcr_strerror(int s) {
 }
 
 const char *pcr_last_error(void) { return g_last_error; }
+
+int pcr_tune(int key, int value) {
+    if (key < 0 || key >= 8) return PCR_E_INVALID;
+    g_tune[key] = value;
+    return PCR_OK;
+}
 
 const char *pcr_version(void) { return "libpcr 0.1 (gfx950, fp64, -ffp-contract=off)"; }
 
@@ -299,6 +453,10 @@ int pcr_ctx_create(int device, pcr_ctx **out) {
     c->block_partials_cap = 0;
     c->result_d = nullptr;
     c->result_h = nullptr;
+    for (int i = 0; i < 6; ++i) {
+        c->scratch_d[i] = nullptr;
+        c->scratch_cap[i] = 0;
+    }
     {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e != hipSuccess) {
@@ -323,6 +481,8 @@ int pcr_ctx_destroy(pcr_ctx *c) {
     if (c->block_partials_d) hipFree(c->block_partials_d);
     if (c->result_d) hipFree(c->result_d);
     if (c->result_h) hipHostFree(c->result_h);
+    for (int i = 0; i < 6; ++i)
+        if (c->scratch_d[i]) hipFree(c->scratch_d[i]);
     if (c->prof) {
         for (int k = 0; k < PCR_PROF_CLASSES; ++k)
             for (int i = 0; i < c->prof->created[k]; ++i) {
@@ -466,6 +626,7 @@ int pcr_index_free(pcr_index *ix) {
     if (ix->tpts_d) hipFree(ix->tpts_d);
     if (ix->cs_d) hipFree(ix->cs_d);
     if (ix->pos_of_d) hipFree(ix->pos_of_d);
+    if (ix->order_d) hipFree(ix->order_d);
     delete ix;
     return PCR_OK;
 }
@@ -549,6 +710,7 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
     BUILD_HIP(hipMalloc(&ix->pts_d, sizeof(Pt4) * (size_t)n));
     BUILD_HIP(hipMalloc(&ix->tpts_d, sizeof(Pt4) * (size_t)n));
     BUILD_HIP(hipMalloc(&ix->pos_of_d, sizeof(uint32_t) * (size_t)n));
+    BUILD_HIP(hipMalloc(&ix->order_d, sizeof(uint32_t) * (size_t)n));
 
     {
         GridView &V = ix->view;
@@ -569,6 +731,8 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
         if (kind == PCR_INDEX_BRUTE) {
             hipLaunchKernelGGL(pack_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, cloud->xyz_d, n,
                                ix->pts_d, ix->pos_of_d);
+            BUILD_HIP(hipMemcpyAsync(ix->order_d, ix->pos_of_d, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice,
+                                     ctx->stream));
             BUILD_HIP(hipStreamSynchronize(ctx->stream));
             ix->info.kind = kind;
             ix->info.n = n;
@@ -661,6 +825,10 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
         V.h = h;
         V.inv_h = G.inv_h;
         for (int a = 0; a < 3; ++a) V.g[a] = G.g[a];
+        // processing order of "all samples": by grid brick, so that a wave's 64 queries share a small box
+        rc = brick_order(ctx, V, ix->pts_d, nullptr, n, ix->order_d, true);
+        if (rc != PCR_OK) goto fail;
+        BUILD_HIP(hipStreamSynchronize(ctx->stream));
         ix->info.kind = kind;
         ix->info.n = n;
         for (int a = 0; a < 3; ++a) ix->info.dims[a] = (uint32_t)G.g[a];

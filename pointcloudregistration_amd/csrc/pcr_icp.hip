@@ -11,7 +11,7 @@
 // kernel folds the block partials in a fixed order (bitwise reproducible run to run).
 #include <math.h>
 #include <string.h>
-#include "knn_device.h"
+#include "wave_search.h"
 
 namespace pcr {
 
@@ -30,6 +30,7 @@ struct StepArgs {
     GridView src, tgt;
     const Pt4 *tsrc;             // transformed source, parallel to src.pts
     const uint32_t *src_pos_of;  // original index -> position in src.pts
+    const uint32_t *src_order;   // positions of src.pts in brick order (processing order of "all samples")
     const uint32_t *sample_idx;  // NULL: samples are positions [sample_begin, sample_begin+m)
     uint32_t sample_begin, m;
     Rigid M;         // current (R,T)
@@ -37,6 +38,7 @@ struct StepArgs {
     int k;
     double thr_fwd, thr_rev;
     uint32_t exact;  // PCR_STEP_EXACT_INDICES
+    int halo0, per_lane;
     double rev_bound_scale, rev_extra_margin;
     double pivot_p[3], pivot_q[3];
     double *block_partials;  // [gridDim.x][17]
@@ -89,65 +91,74 @@ __device__ __forceinline__ void accumulate(double (&acc)[17], bool keep, double 
 
 template <int KC>
 __global__ void __launch_bounds__(256) icp_step_grid_kernel(StepArgs A) {
+    __shared__ Pt4 tiles[4][WAVE_TILE_CAP];
+    __shared__ uint32_t segs[4][2][64];
+    Pt4 *tile = tiles[threadIdx.x >> 6];
+    uint32_t *seg_incl = segs[threadIdx.x >> 6][0], *seg_beg = segs[threadIdx.x >> 6][1];
     const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t t = lb * 256u + threadIdx.x;
+    const bool live = t < A.m;
     double acc[17];
 #pragma unroll
     for (int j = 0; j < 17; ++j) acc[j] = 0.0;
-    if (t < A.m) {
-        uint32_t pos, orig, slot;
+    uint32_t pos = 0, orig = 0, slot = 0;
+    double px = 0, py = 0, pz = 0;
+    if (live) {
         if (A.sample_idx) {
             orig = A.sample_idx[t];
             pos = A.src_pos_of[orig];
             slot = t;
         } else {
-            pos = A.sample_begin + t;
+            pos = A.src_order[A.sample_begin + t];  // brick order: a wave's samples are neighbours in space
             orig = (uint32_t)A.src.pts[pos].w;
             slot = orig;
         }
         const Pt4 s = A.src.pts[pos];
-        double px, py, pz;
         xform(A.M, s.x, s.y, s.z, px, py, pz);  // CurSrcPoint = R*s + T (:86)
+    }
+    // ---- forward: K-th nearest target point of p (:89-92) ----
+    const double fmax_d2 = A.exact ? PCR_INF : A.thr_fwd;
+    const bool fin = live && isfinite(px) && isfinite(py) && isfinite(pz);
+    TopK<KC> top;
+    top.init(fmax_d2);
+    wave_search<KC>(A.tgt, A.tgt.pts, fin, px, py, pz, px, py, pz, fmax_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
+                    tile, seg_incl, seg_beg, A.halo0, A.per_lane != 0);
+    double dF;
+    uint32_t j, jpos;
+    top.slot(A.k, dF, j, jpos);  // NeighborSet.back() = K-th nearest (:91-92)
+    const bool found = fin && j != PCR_NO_INDEX && dF < fmax_d2;
+    const bool passF = found && dF < A.thr_fwd;  // strict < (:97)
 
-        // ---- forward: K-th nearest target point of p (:89-92) ----
-        const double fmax_d2 = A.exact ? PCR_INF : A.thr_fwd;
-        TopK<KC> top;
-        top.init(fmax_d2);
-        if (isfinite(px) && isfinite(py) && isfinite(pz))
-            grid_search<KC>(A.tgt, A.tgt.pts, px, py, pz, px, py, pz, fmax_d2, 1.0 - 1.8189894035458565e-12, 0.0, top);
-        double dF;
-        uint32_t j, jpos;
-        top.slot(A.k, dF, j, jpos);  // NeighborSet.back() = K-th nearest (:91-92)
-        const bool found = j != PCR_NO_INDEX && dF < fmax_d2;
-        const bool passF = found && dF < A.thr_fwd;  // strict < (:97)
-
-        uint32_t r = PCR_NO_INDEX;
-        bool keep = false;
-        double qx = 0, qy = 0, qz = 0;
-        if (found && (passF || A.exact)) {
-            const Pt4 qpt = A.tgt.pts[jpos];
-            qx = qpt.x;
-            qy = qpt.y;
-            qz = qpt.z;
-            // ---- reverse: nearest TRANSFORMED source point of q (:94-95).  The sample's own image p
-            // is a member of that set at distance exactly dF: seeding with it changes nothing and
-            // bounds the search from the start. ----
-            TopK<1> rt;
-            rt.d[0] = dF;
-            rt.idx[0] = orig;
-            rt.pos[0] = pos;
-            const double ux = qx - A.M.t[0], uy = qy - A.M.t[1], uz = qz - A.M.t[2];
-            const double sx = A.rinv[0] * ux + A.rinv[3] * uy + A.rinv[6] * uz;
-            const double sy = A.rinv[1] * ux + A.rinv[4] * uy + A.rinv[7] * uz;
-            const double sz = A.rinv[2] * ux + A.rinv[5] * uy + A.rinv[8] * uz;
-            if (isfinite(sx) && isfinite(sy) && isfinite(sz))
-                grid_search<1>(A.src, A.tsrc, qx, qy, qz, sx, sy, sz, PCR_INF, A.rev_bound_scale,
-                               A.rev_extra_margin, rt);
-            r = rt.idx[0];
-            const Pt4 pp = A.tsrc[rt.pos[0]];
-            const double dR = sqdist3(px, py, pz, pp.x, pp.y, pp.z);  // (CurSrcPoint - TmpPoint).squaredNorm()
-            keep = passF && dR < A.thr_rev;                           // strict < (:98)
-        }
+    // ---- reverse: nearest TRANSFORMED source point of q (:94-95).  The sample's own image p is a member
+    // of that set at distance exactly dF: seeding with it changes nothing and bounds the search. ----
+    const bool need_rev = found && (passF || A.exact);
+    double qx = 0, qy = 0, qz = 0, sx = 0, sy = 0, sz = 0;
+    if (need_rev) {
+        const Pt4 qpt = A.tgt.pts[jpos];
+        qx = qpt.x;
+        qy = qpt.y;
+        qz = qpt.z;
+        const double ux = qx - A.M.t[0], uy = qy - A.M.t[1], uz = qz - A.M.t[2];
+        sx = A.rinv[0] * ux + A.rinv[3] * uy + A.rinv[6] * uz;
+        sy = A.rinv[1] * ux + A.rinv[4] * uy + A.rinv[7] * uz;
+        sz = A.rinv[2] * ux + A.rinv[5] * uy + A.rinv[8] * uz;
+    }
+    TopK<1> rt;
+    rt.d[0] = dF;
+    rt.idx[0] = orig;
+    rt.pos[0] = pos;
+    const bool rev_active = need_rev && isfinite(sx) && isfinite(sy) && isfinite(sz);
+    wave_search<1>(A.src, A.tsrc, rev_active, qx, qy, qz, sx, sy, sz, PCR_INF, A.rev_bound_scale, A.rev_extra_margin,
+                   rt, tile, seg_incl, seg_beg, A.halo0, A.per_lane != 0);
+    uint32_t r = PCR_NO_INDEX;
+    bool keep = false;
+    if (need_rev) {
+        r = rt.idx[0];
+        const Pt4 pp = A.tsrc[rt.pos[0]];
+        const double dR = sqdist3(px, py, pz, pp.x, pp.y, pp.z);  // (CurSrcPoint - TmpPoint).squaredNorm()
+        keep = passF && dR < A.thr_rev;                           // strict < (:98)
+    }
+    if (live) {
         accumulate(acc, keep, px, py, pz, qx, qy, qz, dF, A);
         if (A.out_fwd) A.out_fwd[slot] = found ? j : PCR_NO_INDEX;
         if (A.out_rev) A.out_rev[slot] = r;
@@ -330,6 +341,7 @@ int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
     A.tgt = tgt->view;
     A.tsrc = src->tpts_d;
     A.src_pos_of = src->pos_of_d;
+    A.src_order = src->order_d;
     A.sample_idx = sample_idx_d;
     A.sample_begin = sample_idx_d ? 0 : sample_begin;
     A.m = m;
@@ -339,6 +351,8 @@ int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
     A.thr_fwd = thr_fwd_sq;
     A.thr_rev = thr_rev_sq;
     A.exact = (flags & PCR_STEP_EXACT_INDICES) ? 1u : 0u;
+    A.halo0 = g_tune[1] < 1 ? 1 : g_tune[1];
+    A.per_lane = g_tune[0];
     // |R v| >= sigma_min |v| with sigma_min^2 >= 1 - 3*defect (Gershgorin on R^T R)
     A.rev_bound_scale = (1.0 - 3.0 * defect) * (1.0 - 1.8189894035458565e-12);
     double scale = fabs(T[0]) + fabs(T[1]) + fabs(T[2]);
@@ -448,3 +462,14 @@ int pcr_icp_step(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const
 }
 
 }  // extern "C"
+
+#ifdef PCR_DIAG
+extern "C" int pcr_diag_read_icp(unsigned long long out[16], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcr::g_diag), sizeof(unsigned long long) * 16) != hipSuccess) return -2;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pcr::g_diag), z, sizeof z) != hipSuccess) return -2;
+    }
+    return 0;
+}
+#endif

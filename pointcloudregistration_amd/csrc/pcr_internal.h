@@ -9,6 +9,9 @@
 
 namespace pcr {
 
+// tuning knobs (pcr_tune): 0 search mode (0 wave-cooperative, 1 per-lane), 1 initial halo of the wave box
+extern int g_tune[8];
+
 void set_last_error(const char *fmt, ...);
 
 #define PCR_HIP(call)                                                                          \
@@ -72,6 +75,10 @@ struct pcr_ctx {
     size_t block_partials_cap;  // in doubles
     double *result_d;           // [32] device
     double *result_h;           // [32] pinned host
+    // grow-only device scratch slots (query ordering, temporaries): never freed before the context dies,
+    // so steady-state calls allocate nothing
+    void *scratch_d[6];
+    size_t scratch_cap[6];
 };
 
 namespace pcr {
@@ -97,6 +104,15 @@ struct ProfScope {
 };
 }  // namespace pcr
 
+namespace pcr {
+// returns ctx->scratch_d[slot] grown to at least `bytes` (NULL + last error on failure)
+void *ctx_scratch(pcr_ctx *ctx, int slot, size_t bytes);
+// positions [0,n) ordered by the Morton key of the (>=4x4x4-cell) brick their point falls in; exactly one of
+// pts / xyz_aos is non-NULL.  deterministic: order inside a brick made ascending (index build only).
+int brick_order(pcr_ctx *ctx, const GridView &g, const Pt4 *pts, const double *xyz_aos, uint32_t n,
+                uint32_t *order_d, bool deterministic);
+}  // namespace pcr
+
 struct pcr_cloud {
     pcr_ctx *ctx;
     uint32_t n;
@@ -114,6 +130,7 @@ struct pcr_index {
     pcr::Pt4 *tpts_d;   // [n] same order, transformed by the current (R,T) -- scratch of the ICP step
     uint32_t *cs_d;     // [cells+1]
     uint32_t *pos_of_d; // [n] original index -> position in pts_d
+    uint32_t *order_d;  // [n] positions in pts_d ordered by grid brick: the processing order of "all samples"
     pcr::GridView view;
     pcr_index_info info;
 };

@@ -6,7 +6,7 @@
 // uniform grid, or -- for small clouds -- a tiled brute-force scan with LDS-staged tiles.
 #include <math.h>
 #include <vector>
-#include "knn_device.h"
+#include "wave_search.h"
 
 namespace pcr {
 
@@ -24,18 +24,31 @@ __device__ __forceinline__ void write_result(const TopK<KC> &top, int k, int ord
     }
 }
 
+// One lane per query; the 64 queries of a wave are staged/scanned together (wave_search.h).
+// order (nullable): processing order of the queries (by grid brick), results go to the query's own row.
 template <int KC>
-__global__ void __launch_bounds__(256) knn_grid_kernel(GridView g, const double *__restrict__ q, uint32_t nq, int k,
-                                                       int order, double max_d2, uint32_t *__restrict__ out_idx,
-                                                       double *__restrict__ out_d2) {
-    const uint32_t i = xcd_remap(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
-    if (i >= nq) return;
-    const double qx = q[(size_t)i * 3], qy = q[(size_t)i * 3 + 1], qz = q[(size_t)i * 3 + 2];
+__global__ void __launch_bounds__(256) knn_grid_kernel(GridView g, const double *__restrict__ q,
+                                                       const uint32_t *__restrict__ order, uint32_t nq, int k,
+                                                       int order_out, double max_d2, uint32_t *__restrict__ out_idx,
+                                                       double *__restrict__ out_d2, int halo0, int per_lane) {
+    __shared__ Pt4 tiles[4][WAVE_TILE_CAP];
+    __shared__ uint32_t segs[4][2][64];
+    const uint32_t t = xcd_remap(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
+    const bool live = t < nq;
+    const uint32_t i = live ? (order ? order[t] : t) : 0u;
+    double qx = 0, qy = 0, qz = 0;
+    if (live) {
+        qx = q[(size_t)i * 3];
+        qy = q[(size_t)i * 3 + 1];
+        qz = q[(size_t)i * 3 + 2];
+    }
+    const bool active = live && isfinite(qx) && isfinite(qy) && isfinite(qz);
     TopK<KC> top;
     top.init(max_d2);
-    if (isfinite(qx) && isfinite(qy) && isfinite(qz))
-        grid_search<KC>(g, g.pts, qx, qy, qz, qx, qy, qz, max_d2, 1.0 - 1.8189894035458565e-12, 0.0, top);
-    write_result<KC>(top, k, order, max_d2, out_idx + (size_t)i * k, out_d2 ? out_d2 + (size_t)i * k : nullptr);
+    wave_search<KC>(g, g.pts, active, qx, qy, qz, qx, qy, qz, max_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
+                    tiles[threadIdx.x >> 6], segs[threadIdx.x >> 6][0], segs[threadIdx.x >> 6][1], halo0, per_lane != 0);
+    if (live)
+        write_result<KC>(top, k, order_out, max_d2, out_idx + (size_t)i * k, out_d2 ? out_d2 + (size_t)i * k : nullptr);
 }
 
 constexpr int BRUTE_TILE = 512;  // points per LDS tile: 16 KiB
@@ -75,12 +88,12 @@ __global__ void gather_rows_kernel(const double *__restrict__ xyz, uint32_t firs
 }
 
 template <int KC>
-static void launch_knn(pcr_ctx *ctx, const pcr_index *ix, const double *q_d, uint32_t nq, uint32_t k, int order,
-                       double max_d2, uint32_t *oi_d, double *od_d) {
+static void launch_knn(pcr_ctx *ctx, const pcr_index *ix, const double *q_d, const uint32_t *qorder, uint32_t nq,
+                       uint32_t k, int order, double max_d2, uint32_t *oi_d, double *od_d) {
     const uint32_t nb = (nq + 255) / 256;
     if (ix->kind == PCR_INDEX_GRID)
-        hipLaunchKernelGGL(knn_grid_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, ix->view, q_d, nq, (int)k, order,
-                           max_d2, oi_d, od_d);
+        hipLaunchKernelGGL(knn_grid_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, ix->view, q_d, qorder, nq, (int)k,
+                           order, max_d2, oi_d, od_d, g_tune[1] < 1 ? 1 : g_tune[1], g_tune[0]);
     else
         hipLaunchKernelGGL(knn_brute_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, ix->pts_d, ix->n, q_d, nq,
                            (int)k, order, max_d2, oi_d, od_d);
@@ -107,17 +120,27 @@ int pcr_knn_d(pcr_ctx *ctx, const pcr_index *ix, const double *q_d, uint32_t nq,
     PCR_REQUIRE(q_d, "pcr_knn_d: q_d is NULL");
     PCR_HIP(hipSetDevice(ctx->device));
     if (!(max_d2 >= 0) || isinf(max_d2)) max_d2 = PCR_INF_H;  // negative / NaN / inf: unbounded
+    // Order the queries by grid brick so that each wave's 64 queries share a small box (the callers'
+    // query order is arbitrary); a handful of queries is not worth the extra launches.
+    const uint32_t *qorder = nullptr;
+    if (ix->kind == PCR_INDEX_GRID && nq >= 2048) {
+        uint32_t *o = (uint32_t *)ctx_scratch(ctx, 4, sizeof(uint32_t) * (size_t)nq);
+        if (!o) return PCR_E_NOMEM;
+        int rc = brick_order(ctx, ix->view, nullptr, q_d, nq, o, false);
+        if (rc != PCR_OK) return rc;
+        qorder = o;
+    }
     ProfScope ps(ctx, PCR_PROF_KNN);
     if (k == 1)
-        launch_knn<1>(ctx, ix, q_d, nq, k, order, max_d2, out_idx_d, out_d2_d);
+        launch_knn<1>(ctx, ix, q_d, qorder, nq, k, order, max_d2, out_idx_d, out_d2_d);
     else if (k <= 4)
-        launch_knn<4>(ctx, ix, q_d, nq, k, order, max_d2, out_idx_d, out_d2_d);
+        launch_knn<4>(ctx, ix, q_d, qorder, nq, k, order, max_d2, out_idx_d, out_d2_d);
     else if (k <= 8)
-        launch_knn<8>(ctx, ix, q_d, nq, k, order, max_d2, out_idx_d, out_d2_d);
+        launch_knn<8>(ctx, ix, q_d, qorder, nq, k, order, max_d2, out_idx_d, out_d2_d);
     else if (k <= 16)
-        launch_knn<16>(ctx, ix, q_d, nq, k, order, max_d2, out_idx_d, out_d2_d);
+        launch_knn<16>(ctx, ix, q_d, qorder, nq, k, order, max_d2, out_idx_d, out_d2_d);
     else
-        launch_knn<32>(ctx, ix, q_d, nq, k, order, max_d2, out_idx_d, out_d2_d);
+        launch_knn<32>(ctx, ix, q_d, qorder, nq, k, order, max_d2, out_idx_d, out_d2_d);
     PCR_HIP(hipGetLastError());
     return PCR_OK;
 }
@@ -189,3 +212,14 @@ int pcr_unique_sq_dist(pcr_ctx *ctx, const pcr_index *ix, double *out) {
 }
 
 }  // extern "C"
+
+#ifdef PCR_DIAG
+extern "C" int pcr_diag_read_knn(unsigned long long out[16], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcr::g_diag), sizeof(unsigned long long) * 16) != hipSuccess) return -2;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pcr::g_diag), z, sizeof z) != hipSuccess) return -2;
+    }
+    return 0;
+}
+#endif
