@@ -99,6 +99,8 @@ def main():
     n, k, sdft, ndft = args.points, args.k, 36.0, 4.0
     src, tgt, R_true, t_true = synth.registration_pair(n, n, SEED)
 
+    if os.environ.get("PCR_LIB"):
+        capi.LIB_PATH = os.environ["PCR_LIB"]
     for kv in filter(None, args.tune.split(",")):
         kk, vv = kv.split("=")
         capi.lib().pcr_tune(int(kk), int(vv))

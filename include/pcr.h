@@ -56,8 +56,9 @@ const char *pcr_strerror(int status);
 const char *pcr_last_error(void);
 /* library version string; also names the target ISA it was compiled for */
 const char *pcr_version(void);
-/* Tuning knobs for experiments (no reference counterpart).  key 0: 0 = wave-cooperative search (default),
- * 1 = one lane per query; key 1: initial halo (cells) of the wave box.  Results do not depend on them. */
+/* Tuning knobs for experiments (no reference counterpart).  key 0: 0/1 = one lane per query, pruned ring walk (default), 2 = wave-staged LDS tile search;
+ * 1 = one lane per query; key 1: unused; key 2: log2 of the brick edge used to order queries.
+ * Results do not depend on them. */
 int pcr_tune(int key, int value);
 
 /* ---- context -----------------------------------------------------------------------
@@ -101,7 +102,7 @@ int pcr_cloud_bounds(const pcr_cloud *cloud, double lo[3], double hi[3]);
 typedef enum { PCR_INDEX_AUTO = 0, PCR_INDEX_GRID = 1, PCR_INDEX_BRUTE = 2 } pcr_index_kind;
 typedef struct {
     int kind;                 /* pcr_index_kind; AUTO = BRUTE for n <= brute_max_points    */
-    double target_occupancy;  /* mean points per OCCUPIED cell the build aims at; <=0: 2.0 */
+    double target_occupancy;  /* mean points per OCCUPIED cell the build aims at; <=0: 4.5 */
     double cell_size;         /* > 0 fixes the cell edge and skips the occupancy search   */
     uint64_t max_cells;       /* cap on grid cells (dense cell table); 0: 2^30            */
     uint32_t brute_max_points;/* AUTO threshold; 0: 2048                                  */

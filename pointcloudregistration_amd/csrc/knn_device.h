@@ -34,62 +34,59 @@ __device__ __forceinline__ void xform(const Rigid &M, double x, double y, double
     oz = dadd(dadd(dadd(dmul(M.r[2], x), dmul(M.r[5], y)), dmul(M.r[8], z)), M.t[2]);
 }
 
+// (d, i) before (bd, bi) in the total order (d2, index).  Bitwise operators on purpose: no short-circuit
+// branches in the hot loops.
 __device__ __forceinline__ bool better(double d, uint32_t i, double bd, uint32_t bi) {
-    return d < bd || (d == bd && i < bi);
+    return (d < bd) | ((d == bd) & (i < bi));
 }
 
 // Sorted top-K in registers.  Every access is statically indexed (all loops over KC unroll), so the
 // arrays stay in VGPRs; a search always fills all KC slots -- the K <= KC nearest a caller asked for
-// are the first K of them (same total order), so no run-time K reaches the hot loop.
-// pos = position of the candidate in the array it was read from (to fetch coordinates later).
+// are the first K of them (same total order), so no run-time K reaches the hot loop.  Only (d2, original
+// index) is kept; a caller that needs coordinates looks the position up through the index's pos_of table.
 template <int KC>
 struct TopK {
     double d[KC];
     uint32_t idx[KC];
-    uint32_t pos[KC];
     __device__ __forceinline__ void init(double d0 = PCR_INF) {
 #pragma unroll
         for (int j = 0; j < KC; ++j) {
             d[j] = d0;
             idx[j] = PCR_NO_INDEX;
-            pos[j] = PCR_NO_INDEX;
         }
     }
     __device__ __forceinline__ double worst_d() const { return d[KC - 1]; }
     __device__ __forceinline__ uint32_t worst_i() const { return idx[KC - 1]; }
     // Slot k-1 for a run-time k, WITHOUT a dynamic register index (which would push the arrays to
     // scratch memory): OR together the slots under an all-ones/all-zeros mask.
-    __device__ __forceinline__ void slot(int k, double &od, uint32_t &oi, uint32_t &op) const {
+    __device__ __forceinline__ void slot(int k, double &od, uint32_t &oi) const {
         unsigned long long db = 0;
-        uint32_t ib = 0, pb = 0;
+        uint32_t ib = 0;
 #pragma unroll
         for (int j = 0; j < KC; ++j) {
             const uint32_t m = (uint32_t)0 - (uint32_t)(j == k - 1);
             const unsigned long long m64 = ((unsigned long long)m << 32) | m;
             db |= (unsigned long long)__double_as_longlong(d[j]) & m64;
             ib |= idx[j] & m;
-            pb |= pos[j] & m;
         }
         od = __longlong_as_double((long long)db);
         oi = ib;
-        op = pb;
     }
-    // insert (dist, i, p) keeping the slots sorted ascending by (d, idx); caller has checked that the
-    // candidate beats slot KC-1.
-    __device__ __forceinline__ void insert(double dist, uint32_t i, uint32_t p) {
+    // Insert (dist, i), keeping the slots sorted ascending by (d, idx); the caller has checked that the
+    // candidate beats slot KC-1.  Branch-free: b[j] = "candidate goes before slot j" is monotone in j, and
+    // slot j becomes slot j-1 (shift), the candidate, or stays.
+    __device__ __forceinline__ void insert(double dist, uint32_t i) {
+        bool b[KC];
+#pragma unroll
+        for (int j = 0; j < KC - 1; ++j) b[j] = better(dist, i, d[j], idx[j]);
+        b[KC - 1] = true;
 #pragma unroll
         for (int j = KC - 1; j >= 1; --j) {
-            const bool shift = better(dist, i, d[j - 1], idx[j - 1]);
-            const bool here = !shift && better(dist, i, d[j], idx[j]);
-            d[j] = shift ? d[j - 1] : (here ? dist : d[j]);
-            idx[j] = shift ? idx[j - 1] : (here ? i : idx[j]);
-            pos[j] = shift ? pos[j - 1] : (here ? p : pos[j]);
+            d[j] = b[j - 1] ? d[j - 1] : (b[j] ? dist : d[j]);
+            idx[j] = b[j - 1] ? idx[j - 1] : (b[j] ? i : idx[j]);
         }
-        if (better(dist, i, d[0], idx[0])) {
-            d[0] = dist;
-            idx[0] = i;
-            pos[0] = p;
-        }
+        d[0] = b[0] ? dist : d[0];
+        idx[0] = b[0] ? i : idx[0];
     }
 };
 
@@ -158,7 +155,8 @@ __device__ __forceinline__ double box_bound2(const GridView &g, double sx, doubl
 template <int KC>
 __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__restrict__ cand, double qx, double qy,
                                             double qz, double sx, double sy, double sz, double max_d2,
-                                            double bound_scale, double extra_margin, TopK<KC> &top) {
+                                            double bound_scale, double extra_margin, TopK<KC> &top,
+                                            int r_start = 1) {
     const uint32_t *__restrict__ cs = g.cs;
     const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
     const int cx = cell_coord(sx, g.lo[0], g.inv_h, gx);
@@ -178,10 +176,19 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
     double wd = top.worst_d();
     uint32_t wi = top.worst_i();
 
-    // previously scanned (clamped) box; empty before the first ring
+    // previously scanned (clamped) box; empty before the first ring.  r_start > 1: the caller has already
+    // scanned the cube of radius r_start-1 around the query's cell.
     int px0 = 1, px1 = 0, py0 = 1, py1 = 0, pz0 = 1, pz1 = 0;
+    if (r_start > 1) {
+        px0 = max(cx - (r_start - 1), 0);
+        px1 = min(cx + (r_start - 1), gx - 1);
+        py0 = max(cy - (r_start - 1), 0);
+        py1 = min(cy + (r_start - 1), gy - 1);
+        pz0 = max(cz - (r_start - 1), 0);
+        pz1 = min(cz + (r_start - 1), gz - 1);
+    }
     const int rmax = max(max(gx, gy), gz);
-    for (int r = 1; r <= rmax; ++r) {
+    for (int r = r_start; r <= rmax; ++r) {
         const int x0 = max(cx - r, 0), x1 = min(cx + r, gx - 1);
         const int y0 = max(cy - r, 0), y1 = min(cy + r, gy - 1);
         const int z0 = max(cz - r, 0), z1 = min(cz + r, gz - 1);
@@ -229,7 +236,7 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
             const double d = sqdist3(qx, qy, qz, c.x, c.y, c.z);
             const uint32_t ci = (uint32_t)c.w;
             if (better(d, ci, wd, wi)) {
-                top.insert(d, ci, p);
+                top.insert(d, ci);
                 wd = top.worst_d();
                 wi = top.worst_i();
             }
@@ -251,10 +258,108 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
     }
 }
 
+
+// Ring 1 (the 3x3x3 cells around the query's own cell) straight from global memory, one lane per query,
+// with the same pruning as the tile scan: the nine (y,z) rows are visited centre first, and a row -- or
+// the outer cell of a row -- is skipped once its slab is provably farther than the current K-th best.
+// One loop with a straight-line body (open next row | evaluate one candidate), so the compiler emits a
+// single tight loop.  Returns true if the K-th best is provably final (or the grid is exhausted).
+template <int KC>
+__device__ __forceinline__ bool ring1_pruned(const GridView &g, const Pt4 *__restrict__ cand, double qx, double qy,
+                                             double qz, double sx, double sy, double sz, double max_d2,
+                                             double bound_scale, double extra_margin, TopK<KC> &top) {
+    const uint32_t *__restrict__ cs = g.cs;
+    const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
+    const int cx = cell_coord(sx, g.lo[0], g.inv_h, gx);
+    const int cy = cell_coord(sy, g.lo[1], g.inv_h, gy);
+    const int cz = cell_coord(sz, g.lo[2], g.inv_h, gz);
+    const double margin = g.margin + extra_margin + 9.094947017729282e-13 * (fabs(sx) + fabs(sy) + fabs(sz));
+    double wd = top.worst_d();
+    uint32_t wi = top.worst_i();
+    // squared distance from the query to the slab of cells at offset -1 / +1 along each axis, shrunk by the
+    // safety margin and the bound scale: a slab may be skipped once wd < that value
+    double gl, gh;
+    gl = sx - (g.lo[0] + (double)cx * g.h) - margin;
+    gh = (g.lo[0] + (double)(cx + 1) * g.h) - sx - margin;
+    gl = gl > 0.0 ? gl : 0.0;
+    gh = gh > 0.0 ? gh : 0.0;
+    const double gxl = gl * gl * bound_scale, gxh = gh * gh * bound_scale;
+    gl = sy - (g.lo[1] + (double)cy * g.h) - margin;
+    gh = (g.lo[1] + (double)(cy + 1) * g.h) - sy - margin;
+    gl = gl > 0.0 ? gl : 0.0;
+    gh = gh > 0.0 ? gh : 0.0;
+    const double gyl = gl * gl * bound_scale, gyh = gh * gh * bound_scale;
+    gl = sz - (g.lo[2] + (double)cz * g.h) - margin;
+    gh = (g.lo[2] + (double)(cz + 1) * g.h) - sz - margin;
+    gl = gl > 0.0 ? gl : 0.0;
+    gh = gh > 0.0 ? gh : 0.0;
+    const double gzl = gl * gl * bound_scale, gzh = gh * gh * bound_scale;
+    // rows in order of increasing slab distance class: centre, 4 faces, 4 edges; (dy+1) | (dz+1) << 2
+    const unsigned long long order = 0x5ull | (0x4ull << 4) | (0x6ull << 8) | (0x1ull << 12) | (0x9ull << 16) |
+                                     (0x0ull << 20) | (0x2ull << 24) | (0x8ull << 28) | (0xaull << 32);
+    int ri = 0;
+    uint32_t p = 0, e = 0;
+    bool alive = true;
+    while (alive) {
+        if ((p >= e) & (ri < 9)) {
+            const int code = (int)(order >> (4 * ri)) & 15;
+            ++ri;
+            const int dy = (code & 3) - 1, dz = (code >> 2) - 1;
+            const int ry = cy + dy, rz = cz + dz;
+            const double gy2 = dy < 0 ? gyl : (dy > 0 ? gyh : 0.0);
+            const double gz2 = dz < 0 ? gzl : (dz > 0 ? gzh : 0.0);
+            const double gyz = gy2 + gz2;
+            const bool open = (ry >= 0) & (ry < gy) & (rz >= 0) & (rz < gz) & !(wd < gyz);
+            if (open) {
+                const int xs = (cx > 0) & !(wd < gyz + gxl) ? cx - 1 : cx;
+                const int xe = (cx < gx - 1) & !(wd < gyz + gxh) ? cx + 1 : cx;
+                const size_t base = ((size_t)rz * gy + ry) * gx;
+                p = cs[base + xs];
+                e = cs[base + xe + 1];
+            }
+        }
+        if (p < e) {
+            const Pt4 c = cand[p];
+            ++p;
+            const double d = sqdist3(qx, qy, qz, c.x, c.y, c.z);
+            const uint32_t ci = (uint32_t)c.w;
+            if (better(d, ci, wd, wi)) {
+                top.insert(d, ci);
+                wd = top.worst_d();
+                wi = top.worst_i();
+            }
+        }
+        alive = (p < e) | (ri < 9);
+    }
+    const int lx0 = max(cx - 1, 0), lx1 = min(cx + 1, gx - 1);
+    const int ly0 = max(cy - 1, 0), ly1 = min(cy + 1, gy - 1);
+    const int lz0 = max(cz - 1, 0), lz1 = min(cz + 1, gz - 1);
+    const bool all = (lx0 == 0) & (lx1 == gx - 1) & (ly0 == 0) & (ly1 == gy - 1) & (lz0 == 0) & (lz1 == gz - 1);
+    if (all) return true;
+    double ox = fmax(fmax(g.lo[0] - sx, sx - g.hi[0]), 0.0) - margin;
+    double oy = fmax(fmax(g.lo[1] - sy, sy - g.hi[1]), 0.0) - margin;
+    double oz = fmax(fmax(g.lo[2] - sz, sz - g.hi[2]), 0.0) - margin;
+    ox = ox > 0.0 ? ox : 0.0;
+    oy = oy > 0.0 ? oy : 0.0;
+    oz = oz > 0.0 ? oz : 0.0;
+    const double b2 =
+        box_bound2(g, sx, sy, sz, margin, ox * ox, oy * oy, oz * oz, lx0, lx1, ly0, ly1, lz0, lz1) * bound_scale;
+    return (wd < b2) | (max_d2 <= b2);
+}
+
+// The per-lane search the kernels use: pruned ring 1, then (rarely) the generic shells from ring 2 on.
+template <int KC>
+__device__ __forceinline__ void lane_search(const GridView &g, const Pt4 *__restrict__ cand, double qx, double qy,
+                                            double qz, double sx, double sy, double sz, double max_d2,
+                                            double bound_scale, double extra_margin, TopK<KC> &top) {
+    if (!ring1_pruned<KC>(g, cand, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top))
+        grid_search<KC>(g, cand, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, 2);
+}
+
 // Brute-force scan of one LDS tile (all lanes read the same address: LDS broadcast).
 template <int KC>
-__device__ __forceinline__ void tile_scan(const Pt4 *tile, int count, uint32_t pos_base, double qx, double qy,
-                                          double qz, TopK<KC> &top) {
+__device__ __forceinline__ void tile_scan(const Pt4 *tile, int count, double qx, double qy, double qz,
+                                          TopK<KC> &top) {
     double wd = top.worst_d();
     uint32_t wi = top.worst_i();
     for (int j = 0; j < count; ++j) {
@@ -262,7 +367,7 @@ __device__ __forceinline__ void tile_scan(const Pt4 *tile, int count, uint32_t p
         const double d = sqdist3(qx, qy, qz, c.x, c.y, c.z);
         const uint32_t ci = (uint32_t)c.w;
         if (better(d, ci, wd, wi)) {
-            top.insert(d, ci, pos_base + j);
+            top.insert(d, ci);
             wd = top.worst_d();
             wi = top.worst_i();
         }

@@ -13,7 +13,7 @@
 namespace pcr {
 
 static thread_local char g_last_error[512] = "";
-int g_tune[8] = {0, 1, 0, 0, 0, 0, 0, 0};
+int g_tune[8] = {0, 1, 0, 0, 0, 0, 0, 0};  // [0] 0/1: per-lane search (default), 2: LDS tile search
 
 void set_last_error(const char *fmt, ...) {
     va_list ap;
@@ -363,14 +363,14 @@ int brick_order(pcr_ctx *ctx, const GridView &g, const Pt4 *pts, const double *x
         B.G.g[a] = g.g[a];
     }
     B.G.inv_h = g.inv_h;
-    B.shift = 2;
+    B.shift = g_tune[2] > 0 ? g_tune[2] : 1;
     uint64_t nbricks;
-    for (;;) {  // Morton key space 2^(3*bits) <= 2^24 entries: grow the brick until 8 bits per axis suffice
+    for (;;) {  // Morton key space 2^(3*bits) <= 2^21 entries: grow the brick until 7 bits per axis suffice
         int maxnb = 1;
         for (int a = 0; a < 3; ++a) maxnb = maxnb > ((g.g[a] - 1) >> B.shift) + 1 ? maxnb : ((g.g[a] - 1) >> B.shift) + 1;
         B.bits = 1;
         while ((1 << B.bits) < maxnb) ++B.bits;
-        if (B.bits <= 8) break;
+        if (B.bits <= 7) break;
         ++B.shift;
     }
     nbricks = 1ull << (3 * B.bits);
@@ -678,7 +678,7 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
     pcr_index_params P;
     memset(&P, 0, sizeof P);
     if (params) P = *params;
-    if (!(P.target_occupancy > 0)) P.target_occupancy = 2.0;
+    if (!(P.target_occupancy > 0)) P.target_occupancy = 4.5;
     if (P.max_cells == 0) P.max_cells = 1ull << 30;
     if (P.max_cells > (1ull << 32) - 8) P.max_cells = (1ull << 32) - 8;
     if (P.brute_max_points == 0) P.brute_max_points = 2048;
@@ -724,6 +724,7 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
         V.margin = 9.094947017729282e-13 * (scale + maxext);  // 2^-40 of the coordinate scale
         V.n = n;
         V.pts = ix->pts_d;
+        V.pos_of = ix->pos_of_d;
         V.cs = nullptr;
         V.h = V.inv_h = 1.0;
         V.g[0] = V.g[1] = V.g[2] = 1;

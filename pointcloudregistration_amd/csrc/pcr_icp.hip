@@ -11,7 +11,10 @@
 // kernel folds the block partials in a fixed order (bitwise reproducible run to run).
 #include <math.h>
 #include <string.h>
-#include "wave_search.h"
+#include "tile_search.h"
+#ifndef PCR_STEP_WAVES
+#define PCR_STEP_WAVES 4
+#endif
 
 namespace pcr {
 
@@ -89,12 +92,8 @@ __device__ __forceinline__ void accumulate(double (&acc)[17], bool keep, double 
     acc[16] = keep ? dF : 0.0;
 }
 
-template <int KC>
-__global__ void __launch_bounds__(256) icp_step_grid_kernel(StepArgs A) {
-    __shared__ Pt4 tiles[4][WAVE_TILE_CAP];
-    __shared__ uint32_t segs[4][2][64];
-    Pt4 *tile = tiles[threadIdx.x >> 6];
-    uint32_t *seg_incl = segs[threadIdx.x >> 6][0], *seg_beg = segs[threadIdx.x >> 6][1];
+template <int KC, bool TILE>
+__global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(StepArgs A) {
     const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t t = lb * 256u + threadIdx.x;
     const bool live = t < A.m;
@@ -121,11 +120,19 @@ __global__ void __launch_bounds__(256) icp_step_grid_kernel(StepArgs A) {
     const bool fin = live && isfinite(px) && isfinite(py) && isfinite(pz);
     TopK<KC> top;
     top.init(fmax_d2);
-    wave_search<KC>(A.tgt, A.tgt.pts, fin, px, py, pz, px, py, pz, fmax_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
-                    tile, seg_incl, seg_beg, A.halo0, A.per_lane != 0);
+    WaveTile *tile = nullptr;
+    if constexpr (TILE) {
+        __shared__ WaveTile tiles[4];
+        tile = &tiles[threadIdx.x >> 6];
+        tile_search<KC>(A.tgt, A.tgt.pts, fin, px, py, pz, px, py, pz, fmax_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
+                        *tile, false);
+    } else {
+        if (fin)
+            lane_search<KC>(A.tgt, A.tgt.pts, px, py, pz, px, py, pz, fmax_d2, 1.0 - 1.8189894035458565e-12, 0.0, top);
+    }
     double dF;
-    uint32_t j, jpos;
-    top.slot(A.k, dF, j, jpos);  // NeighborSet.back() = K-th nearest (:91-92)
+    uint32_t j;
+    top.slot(A.k, dF, j);  // NeighborSet.back() = K-th nearest (:91-92)
     const bool found = fin && j != PCR_NO_INDEX && dF < fmax_d2;
     const bool passF = found && dF < A.thr_fwd;  // strict < (:97)
 
@@ -134,7 +141,7 @@ __global__ void __launch_bounds__(256) icp_step_grid_kernel(StepArgs A) {
     const bool need_rev = found && (passF || A.exact);
     double qx = 0, qy = 0, qz = 0, sx = 0, sy = 0, sz = 0;
     if (need_rev) {
-        const Pt4 qpt = A.tgt.pts[jpos];
+        const Pt4 qpt = A.tgt.pts[A.tgt.pos_of[j]];
         qx = qpt.x;
         qy = qpt.y;
         qz = qpt.z;
@@ -146,15 +153,19 @@ __global__ void __launch_bounds__(256) icp_step_grid_kernel(StepArgs A) {
     TopK<1> rt;
     rt.d[0] = dF;
     rt.idx[0] = orig;
-    rt.pos[0] = pos;
     const bool rev_active = need_rev && isfinite(sx) && isfinite(sy) && isfinite(sz);
-    wave_search<1>(A.src, A.tsrc, rev_active, qx, qy, qz, sx, sy, sz, PCR_INF, A.rev_bound_scale, A.rev_extra_margin,
-                   rt, tile, seg_incl, seg_beg, A.halo0, A.per_lane != 0);
+    if constexpr (TILE) {
+        tile_search<1>(A.src, A.tsrc, rev_active, qx, qy, qz, sx, sy, sz, PCR_INF, A.rev_bound_scale,
+                       A.rev_extra_margin, rt, *tile, false);
+    } else {
+        if (rev_active)
+            lane_search<1>(A.src, A.tsrc, qx, qy, qz, sx, sy, sz, PCR_INF, A.rev_bound_scale, A.rev_extra_margin, rt);
+    }
     uint32_t r = PCR_NO_INDEX;
     bool keep = false;
     if (need_rev) {
         r = rt.idx[0];
-        const Pt4 pp = A.tsrc[rt.pos[0]];
+        const Pt4 pp = A.tsrc[r == orig ? pos : A.src_pos_of[r]];
         const double dR = sqdist3(px, py, pz, pp.x, pp.y, pp.z);  // (CurSrcPoint - TmpPoint).squaredNorm()
         keep = passF && dR < A.thr_rev;                           // strict < (:98)
     }
@@ -198,17 +209,17 @@ __global__ void __launch_bounds__(256) icp_step_brute_kernel(StepArgs A) {
         const int cnt = (int)min(512u, A.tgt.n - base);
         for (int u = threadIdx.x; u < cnt; u += 256) tile[u] = A.tgt.pts[base + u];
         __syncthreads();
-        if (fin) tile_scan<KC>(tile, cnt, base, px, py, pz, top);
+        if (fin) tile_scan<KC>(tile, cnt, px, py, pz, top);
         __syncthreads();
     }
     double dF;
-    uint32_t j, jpos;
-    top.slot(A.k, dF, j, jpos);
+    uint32_t j;
+    top.slot(A.k, dF, j);
     const bool found = fin && j != PCR_NO_INDEX;
     const bool passF = found && dF < A.thr_fwd;
     double qx = 0, qy = 0, qz = 0;
     if (found) {
-        const Pt4 qpt = A.tgt.pts[jpos];
+        const Pt4 qpt = A.tgt.pts[A.tgt.pos_of[j]];
         qx = qpt.x;
         qy = qpt.y;
         qz = qpt.z;
@@ -216,19 +227,18 @@ __global__ void __launch_bounds__(256) icp_step_brute_kernel(StepArgs A) {
     TopK<1> rt;
     rt.d[0] = found ? dF : PCR_INF;
     rt.idx[0] = found ? orig : PCR_NO_INDEX;
-    rt.pos[0] = pos;
     for (uint32_t base = 0; base < A.src.n; base += 512) {
         const int cnt = (int)min(512u, A.src.n - base);
         for (int u = threadIdx.x; u < cnt; u += 256) tile[u] = A.tsrc[base + u];
         __syncthreads();
-        if (found) tile_scan<1>(tile, cnt, base, qx, qy, qz, rt);
+        if (found) tile_scan<1>(tile, cnt, qx, qy, qz, rt);
         __syncthreads();
     }
     bool keep = false;
     uint32_t r = PCR_NO_INDEX;
     if (found) {
         r = rt.idx[0];
-        const Pt4 pp = A.tsrc[rt.pos[0]];
+        const Pt4 pp = A.tsrc[A.src_pos_of[r]];
         const double dR = sqdist3(px, py, pz, pp.x, pp.y, pp.z);
         keep = passF && dR < A.thr_rev;
     }
@@ -389,8 +399,10 @@ int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
     }
 #define LAUNCH_STEP(KC)                                                                                           \
     do {                                                                                                          \
-        if (src->kind == PCR_INDEX_GRID)                                                                          \
-            hipLaunchKernelGGL(icp_step_grid_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, A);                 \
+        if (src->kind == PCR_INDEX_GRID && g_tune[0] == 2)                                                        \
+            hipLaunchKernelGGL((icp_step_grid_kernel<KC, true>), dim3(nb), dim3(256), 0, ctx->stream, A);         \
+        else if (src->kind == PCR_INDEX_GRID)                                                                     \
+            hipLaunchKernelGGL((icp_step_grid_kernel<KC, false>), dim3(nb), dim3(256), 0, ctx->stream, A);        \
         else                                                                                                      \
             hipLaunchKernelGGL(icp_step_brute_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, A);                \
     } while (0)

@@ -43,6 +43,7 @@ struct __attribute__((aligned(32))) Pt4 {
 struct GridView {
     const Pt4 *pts;       // [n] in cell order (GRID) or in original order (BRUTE)
     const uint32_t *cs;   // [cells+1] exclusive cell starts; NULL for BRUTE
+    const uint32_t *pos_of;  // [n] original index -> position in pts
     double lo[3], hi[3];  // bounds of the points
     double h, inv_h;      // cell edge
     double margin;        // absolute safety margin on face distances, ~2^-40 * coordinate scale

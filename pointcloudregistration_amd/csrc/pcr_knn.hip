@@ -6,7 +6,7 @@
 // uniform grid, or -- for small clouds -- a tiled brute-force scan with LDS-staged tiles.
 #include <math.h>
 #include <vector>
-#include "wave_search.h"
+#include "tile_search.h"
 
 namespace pcr {
 
@@ -26,13 +26,11 @@ __device__ __forceinline__ void write_result(const TopK<KC> &top, int k, int ord
 
 // One lane per query; the 64 queries of a wave are staged/scanned together (wave_search.h).
 // order (nullable): processing order of the queries (by grid brick), results go to the query's own row.
-template <int KC>
+template <int KC, bool TILE>
 __global__ void __launch_bounds__(256) knn_grid_kernel(GridView g, const double *__restrict__ q,
                                                        const uint32_t *__restrict__ order, uint32_t nq, int k,
                                                        int order_out, double max_d2, uint32_t *__restrict__ out_idx,
-                                                       double *__restrict__ out_d2, int halo0, int per_lane) {
-    __shared__ Pt4 tiles[4][WAVE_TILE_CAP];
-    __shared__ uint32_t segs[4][2][64];
+                                                       double *__restrict__ out_d2) {
     const uint32_t t = xcd_remap(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
     const bool live = t < nq;
     const uint32_t i = live ? (order ? order[t] : t) : 0u;
@@ -45,8 +43,14 @@ __global__ void __launch_bounds__(256) knn_grid_kernel(GridView g, const double 
     const bool active = live && isfinite(qx) && isfinite(qy) && isfinite(qz);
     TopK<KC> top;
     top.init(max_d2);
-    wave_search<KC>(g, g.pts, active, qx, qy, qz, qx, qy, qz, max_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
-                    tiles[threadIdx.x >> 6], segs[threadIdx.x >> 6][0], segs[threadIdx.x >> 6][1], halo0, per_lane != 0);
+    if constexpr (TILE) {
+        __shared__ WaveTile tiles[4];
+        tile_search<KC>(g, g.pts, active, qx, qy, qz, qx, qy, qz, max_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
+                        tiles[threadIdx.x >> 6], false);
+    } else {
+        if (active)
+            lane_search<KC>(g, g.pts, qx, qy, qz, qx, qy, qz, max_d2, 1.0 - 1.8189894035458565e-12, 0.0, top);
+    }
     if (live)
         write_result<KC>(top, k, order_out, max_d2, out_idx + (size_t)i * k, out_d2 ? out_d2 + (size_t)i * k : nullptr);
 }
@@ -74,7 +78,7 @@ __global__ void __launch_bounds__(256) knn_brute_kernel(const Pt4 *__restrict__ 
         const int cnt = (int)min((uint32_t)BRUTE_TILE, n - base);
         for (int t = threadIdx.x; t < cnt; t += 256) tile[t] = pts[base + t];  // coalesced 32-B rows
         __syncthreads();
-        if (live && fin) tile_scan<KC>(tile, cnt, base, qx, qy, qz, top);
+        if (live && fin) tile_scan<KC>(tile, cnt, qx, qy, qz, top);
         __syncthreads();
     }
     if (live)
@@ -91,9 +95,12 @@ template <int KC>
 static void launch_knn(pcr_ctx *ctx, const pcr_index *ix, const double *q_d, const uint32_t *qorder, uint32_t nq,
                        uint32_t k, int order, double max_d2, uint32_t *oi_d, double *od_d) {
     const uint32_t nb = (nq + 255) / 256;
-    if (ix->kind == PCR_INDEX_GRID)
-        hipLaunchKernelGGL(knn_grid_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, ix->view, q_d, qorder, nq, (int)k,
-                           order, max_d2, oi_d, od_d, g_tune[1] < 1 ? 1 : g_tune[1], g_tune[0]);
+    if (ix->kind == PCR_INDEX_GRID && g_tune[0] == 2)
+        hipLaunchKernelGGL((knn_grid_kernel<KC, true>), dim3(nb), dim3(256), 0, ctx->stream, ix->view, q_d, qorder, nq,
+                           (int)k, order, max_d2, oi_d, od_d);
+    else if (ix->kind == PCR_INDEX_GRID)
+        hipLaunchKernelGGL((knn_grid_kernel<KC, false>), dim3(nb), dim3(256), 0, ctx->stream, ix->view, q_d, qorder, nq,
+                           (int)k, order, max_d2, oi_d, od_d);
     else
         hipLaunchKernelGGL(knn_brute_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, ix->pts_d, ix->n, q_d, nq,
                            (int)k, order, max_d2, oi_d, od_d);

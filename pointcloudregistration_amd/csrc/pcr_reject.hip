@@ -35,7 +35,7 @@ __device__ __forceinline__ double sq_dist_to_centroid(const GridView &g, double 
         if (j < k) {
             open = open && top.idx[j] != PCR_NO_INDEX && top.d[j] < msd;
             if (open) {
-                const Pt4 p = g.pts[top.pos[j]];
+                const Pt4 p = g.pts[g.pos_of[top.idx[j]]];
                 c0 += p.x;
                 c1 += p.y;
                 c2 += p.z;
@@ -79,7 +79,7 @@ __device__ __forceinline__ double sq_dist_to_centroid_brute(const GridView &g, d
         const Pt4 c = g.pts[j];
         const double d = sqdist3(x, y, z, c.x, c.y, c.z);
         if (better(d, (uint32_t)c.w, wd, wi)) {
-            top.insert(d, (uint32_t)c.w, j);
+            top.insert(d, (uint32_t)c.w);
             wd = top.worst_d();
             wi = top.worst_i();
         }
@@ -92,7 +92,7 @@ __device__ __forceinline__ double sq_dist_to_centroid_brute(const GridView &g, d
         if (j < k) {
             open = open && top.idx[j] != PCR_NO_INDEX && top.d[j] < msd;
             if (open) {
-                const Pt4 p = g.pts[top.pos[j]];
+                const Pt4 p = g.pts[g.pos_of[top.idx[j]]];
                 c0 += p.x;
                 c1 += p.y;
                 c2 += p.z;
