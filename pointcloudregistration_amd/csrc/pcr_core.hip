@@ -288,21 +288,34 @@ __global__ void __launch_bounds__(256) brick_scatter_kernel(const uint32_t *__re
         order[atomicAdd(&cursor[brick_id[i]], 1u)] = i;
 }
 
-// after the scatter cursor[b] == end of brick b; start = end of the previous brick
+// After the scatter cursor[b] == end of brick b; start = end of the previous brick.  The scatter's atomics
+// leave the order inside a brick to chance; make it ascending so that the processing order (and with it
+// the order of every floating-point sum) is the same on every run.  One WAVE per brick, rank sort: the
+// values are distinct, so rank = number of smaller values is a permutation.
+constexpr int BRICK_SORT_CAP = 1024;
 __global__ void __launch_bounds__(256) brick_sort_kernel(const uint32_t *__restrict__ ends, uint32_t nbricks,
                                                          uint32_t *__restrict__ order) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nbricks) return;
-    const uint32_t beg = b ? ends[b - 1] : 0u, end = ends[b];
-    if (end - beg < 2 || end - beg > 2048) return;
-    for (uint32_t i = beg + 1; i < end; ++i) {
-        const uint32_t v = order[i];
-        uint32_t j = i;
-        while (j > beg && order[j - 1] > v) {
-            order[j] = order[j - 1];
-            --j;
+    __shared__ uint32_t sm[4][BRICK_SORT_CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nwaves = gridDim.x * 4u;
+    uint32_t *buf = sm[wave];
+    for (uint32_t b = blockIdx.x * 4u + wave; b < nbricks; b += nwaves) {
+        const uint32_t beg = b ? ends[b - 1] : 0u, end = ends[b];
+        const uint32_t len = end - beg;
+        if (len < 2 || len > BRICK_SORT_CAP) continue;  // wave-uniform
+        for (uint32_t i = lane; i < len; i += 64) buf[i] = order[beg + i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t i = lane; i < len; i += 64) {
+            const uint32_t v = buf[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < len; ++j) rank += buf[j] < v;
+            order[beg + rank] = v;
         }
-        order[j] = v;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -391,8 +404,8 @@ int brick_order(pcr_ctx *ctx, const GridView &g, const Pt4 *pts, const double *x
     hipLaunchKernelGGL(brick_scatter_kernel, dim3(grid_blocks(n)), dim3(256), 0, ctx->stream, brick_id, n, counts,
                        order_d);
     if (deterministic)
-        hipLaunchKernelGGL(brick_sort_kernel, dim3((unsigned)((nbricks + 255) / 256)), dim3(256), 0, ctx->stream,
-                           counts, (uint32_t)nbricks, order_d);
+        hipLaunchKernelGGL(brick_sort_kernel, dim3(2048), dim3(256), 0, ctx->stream, counts, (uint32_t)nbricks,
+                           order_d);
     PCR_HIP(hipGetLastError());
     return PCR_OK;
 }

@@ -44,13 +44,15 @@ struct StepArgs {
     int halo0, per_lane;
     double rev_bound_scale, rev_extra_margin;
     double pivot_p[3], pivot_q[3];
-    double *block_partials;  // [gridDim.x][17]
+    double *block_partials;  // [17][gridDim.x]
     uint32_t *out_fwd, *out_rev;
     uint8_t *out_keep;
 };
 
-// 17 per-lane values -> one row per block.  Wave reduction by shuffles, then LDS across the 4 waves.
-__device__ __forceinline__ void block_reduce17(double (&v)[17], double *__restrict__ out_row) {
+// 17 per-lane values -> one value per block and column, stored column-major [17][nblocks] so that the fold
+// reads coalesced.  Wave reduction by shuffles, then LDS across the 4 waves.
+__device__ __forceinline__ void block_reduce17(double (&v)[17], double *__restrict__ out, uint32_t block,
+                                               uint32_t nblocks) {
     __shared__ double sm[4][17];
 #pragma unroll
     for (int j = 0; j < 17; ++j) {
@@ -65,7 +67,9 @@ __device__ __forceinline__ void block_reduce17(double (&v)[17], double *__restri
         for (int j = 0; j < 17; ++j) sm[wave][j] = v[j];
     }
     __syncthreads();
-    if (threadIdx.x < 17) out_row[threadIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+    if (threadIdx.x < 17)
+        out[(size_t)threadIdx.x * nblocks + block] =
+            (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
 
 __device__ __forceinline__ void accumulate(double (&acc)[17], bool keep, double px, double py, double pz, double qx,
@@ -175,7 +179,7 @@ __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(Step
         if (A.out_rev) A.out_rev[slot] = r;
         if (A.out_keep) A.out_keep[slot] = keep ? 1 : 0;
     }
-    block_reduce17(acc, A.block_partials + (size_t)lb * 17);
+    block_reduce17(acc, A.block_partials, lb, gridDim.x);
 }
 
 // Small clouds: both searches as tiled brute force (LDS-staged tiles, broadcast reads).
@@ -248,26 +252,25 @@ __global__ void __launch_bounds__(256) icp_step_brute_kernel(StepArgs A) {
         if (A.out_rev) A.out_rev[slot] = r;
         if (A.out_keep) A.out_keep[slot] = keep ? 1 : 0;
     }
-    block_reduce17(acc, A.block_partials + (size_t)blockIdx.x * 17);
+    block_reduce17(acc, A.block_partials, blockIdx.x, gridDim.x);
 }
 
-// Fold the block rows in a fixed order: lane j%... each of 256 threads strides over the rows, then a
-// tree over the 256 partial rows.  Same order every run => bitwise reproducible.
-__global__ void __launch_bounds__(256) fold_partials_kernel(const double *__restrict__ rows, uint32_t nrows,
+// Fold the block partials in a fixed order: block j of the grid owns column j (one of the 17 sums); its 256
+// threads stride over the blocks' values (coalesced), then a tree.  Same order every run => the sums are
+// bitwise reproducible run to run.
+__global__ void __launch_bounds__(256) fold_partials_kernel(const double *__restrict__ cols, uint32_t nblocks,
                                                             double *__restrict__ out /*[17]*/) {
     __shared__ double sm[256];
-    for (int j = 0; j < 17; ++j) {
-        double s = 0.0;
-        for (uint32_t r = threadIdx.x; r < nrows; r += 256) s += rows[(size_t)r * 17 + j];
-        sm[threadIdx.x] = s;
-        __syncthreads();
-        for (int w = 128; w > 0; w >>= 1) {
-            if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) out[j] = sm[0];
+    const double *col = cols + (size_t)blockIdx.x * nblocks;
+    double s = 0.0;
+    for (uint32_t r = threadIdx.x; r < nblocks; r += 256) s += col[r];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
         __syncthreads();
     }
+    if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
 }
 
 static bool invert3(const double R[9], double inv[9], double &defect) {
@@ -422,7 +425,7 @@ int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
 #undef LAUNCH_STEP
     {
         ProfScope ps(ctx, PCR_PROF_FOLD);
-        hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(17), dim3(256), 0, ctx->stream,
                            (const double *)ctx->block_partials_d, nb, partials_d);
     }
     PCR_HIP(hipGetLastError());
