@@ -35,6 +35,27 @@ def algorithmic_bytes_per_sample(k):
     return 56 + 24 * k
 
 
+def committed_traffic(kernel_prefix, points, k):
+    """HBM bytes per launch of the step kernel from the PMC passes committed under profiles/ (FETCH_SIZE x 2
+    [gfx950 correction] + WRITE_SIZE, see tools/summarize_profile.py).  Counters cannot be collected from
+    inside this process; the figure is from `rocprofv3 --pmc` runs of this same command (tools/profile.sh)
+    and only applies to the headline workload it was collected on -- otherwise None."""
+    if points != 1_000_000 or k != 4:
+        return None, None
+    import glob
+    best = (None, None)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            with open(f) as fh:
+                d = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        for name, e in d.get("kernels", {}).items():
+            if name.startswith(kernel_prefix) and "hbm_traffic_bytes" in e:
+                best = (e["hbm_traffic_bytes"], os.path.relpath(f, ROOT))
+    return best
+
+
 def cpu_baseline(src, tgt, R0, T0, k, sdft, ndft, budget_s=25.0):
     """The oracle (CPU restatement of the reference loop) timed on this box's host cores -- the CHECKER
     timed as a baseline, never the thing measured above.  Per iteration it does what the reference does:
@@ -182,6 +203,7 @@ def main():
         algo_bytes = algorithmic_bytes_per_sample(k) * m
         achieved = algo_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
         info = tix.info()
+        traffic, traffic_src = committed_traffic("icp_step_grid_kernel<%d" % k, n, k) if world == 1 else (None, None)
         out = {
             "metric": "icp_iterations_per_s", "value": args.steps / elapsed, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -194,7 +216,8 @@ def main():
                        "points_per_cloud": n, "k": k, "parallelism": f"sample-sharded x{world}, clouds+indices "
                        "replicated, 17-double all-reduce per iteration"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernel": f"icp_step_grid_kernel<{k if k in (1, 4, 8, 16, 32) else '>=k'}>",
                          "kernel_ms_avg": step_ms, "launches": kt["step"][1],
                          "algorithmic_bytes_per_launch": algo_bytes,
