@@ -184,6 +184,16 @@ int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src_index, const pcr_index *tg
 int pcr_icp_pivots(const pcr_index *src_index, const pcr_index *tgt_index, const double R[9],
                    const double T[3], double pivot_p[3], double pivot_q[3]);
 
+/* ---- the same 17 sums over an EXPLICIT pair list ------------------------------------------
+ * Replaces compute3DCentroid x2 + __deMean + __buildPointPairMatrix + H = A*B^T
+ * (RegUtilityFunctions.cpp:44-72, TransformationEstimationSVD2.cpp:33-103) and __calculateMSE
+ * (DefaultConvergenceCriterial.cpp:46-65) when the pairs already exist on the host -- the public
+ * CTransformationEstimationSVD2::computeRotationAndTranslation(A, B, R, T) overload
+ * (TransformationEstimationSVD2.cpp:33-49), or the output of a rejection stage.  pair_p, pair_q: AoS
+ * double[3P]; pivots as in pcr_icp_step (any point near the data, e.g. the first pair). */
+int pcr_reduce_pairs(pcr_ctx *ctx, const double *pair_p, const double *pair_q, uint32_t P, const double pivot_p[3],
+                     const double pivot_q[3], double partials[17]);
+
 /* ---- host: CTransformationEstimationSVD2::__computeRelativeRotationAndTranslation
  *      (TransformationEstimationSVD2.cpp:98-117) + accumulateTransformation
  *      (BaseTransformationEstimation.h:28-32), fed by the 17 partials instead of pair lists.

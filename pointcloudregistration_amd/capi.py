@@ -71,6 +71,7 @@ SYMBOLS = {
     "pcr_icp_step_d": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _dp, _dp, C.c_uint32, C.c_double,
                                  C.c_double, C.c_uint32, _vp, _vp, _vp, _vp]),
     "pcr_icp_pivots": (C.c_int, [_vp, _vp, _dp, _dp, _dp, _dp]),
+    "pcr_reduce_pairs": (C.c_int, [_vp, _dp, _dp, C.c_uint32, _dp, _dp, _dp]),
     "pcr_solve_rigid": (C.c_int, [_dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "pcr_reject_centroid_dist": (C.c_int, [_vp, _vp, _vp, _dp, _dp, C.c_uint32, C.c_uint32, C.c_double, C.c_double,
                                            _bp, _dp, _dp]),
@@ -278,6 +279,17 @@ def icp_pivots(src_index, tgt_index, R, T):
     pp, pq = np.empty(3), np.empty(3)
     _check(lib().pcr_icp_pivots(src_index.h, tgt_index.h, _d(R), _d(T), _d(pp), _d(pq)), "pcr_icp_pivots")
     return pp, pq
+
+
+def reduce_pairs(ctx, pair_p, pair_q, pivot_p=None, pivot_q=None):
+    """The 17 partial sums of an explicit pair list, reduced on the device.  Returns (partials, pivot_p, pivot_q)."""
+    pp, pq = _f64(pair_p), _f64(pair_q)
+    assert pp.shape == pq.shape
+    pivot_p = np.ascontiguousarray(pp[0] if pivot_p is None and len(pp) else (pivot_p if pivot_p is not None else np.zeros(3)), np.float64).reshape(3).copy()
+    pivot_q = np.ascontiguousarray(pq[0] if pivot_q is None and len(pq) else (pivot_q if pivot_q is not None else np.zeros(3)), np.float64).reshape(3).copy()
+    out = np.empty(17)
+    _check(lib().pcr_reduce_pairs(ctx.h, _d(pp), _d(pq), len(pp), _d(pivot_p), _d(pivot_q), _d(out)), "pcr_reduce_pairs")
+    return out, pivot_p, pivot_q
 
 
 def solve_rigid(partials, pivot_p, pivot_q, R, T):

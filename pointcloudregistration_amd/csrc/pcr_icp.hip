@@ -273,6 +273,22 @@ __global__ void __launch_bounds__(256) fold_partials_kernel(const double *__rest
     if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
 }
 
+// Pair lists that already exist (a host-side rejection stage produced them): the same 17 sums over P explicit
+// pairs, same block reduction and fold.  pairs are AoS double[3P].
+__global__ void __launch_bounds__(256) reduce_pairs_kernel(const double *__restrict__ pp, const double *__restrict__ pq,
+                                                           uint32_t P, StepArgs A) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    double acc[17];
+#pragma unroll
+    for (int j = 0; j < 17; ++j) acc[j] = 0.0;
+    if (t < P) {
+        const double px = pp[3 * (size_t)t], py = pp[3 * (size_t)t + 1], pz = pp[3 * (size_t)t + 2];
+        const double qx = pq[3 * (size_t)t], qy = pq[3 * (size_t)t + 1], qz = pq[3 * (size_t)t + 2];
+        accumulate(acc, true, px, py, pz, qx, qy, qz, sqdist3(px, py, pz, qx, qy, qz), A);
+    }
+    block_reduce17(acc, A.block_partials, blockIdx.x, gridDim.x);
+}
+
 static bool invert3(const double R[9], double inv[9], double &defect) {
     // column-major: R(r,c) = R[c*3+r]
     auto at = [&](int r, int c) { return R[c * 3 + r]; };
@@ -472,6 +488,44 @@ int pcr_icp_step(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const
     if (r_d) hipFree(r_d);
     if (k_d) hipFree(k_d);
     if (rc != PCR_OK) return rc;
+    PCR_HIP(e);
+    return PCR_OK;
+}
+
+int pcr_reduce_pairs(pcr_ctx *ctx, const double *pair_p, const double *pair_q, uint32_t P, const double pivot_p[3],
+                     const double pivot_q[3], double partials[17]) {
+    PCR_REQUIRE(ctx && partials && pivot_p && pivot_q, "pcr_reduce_pairs: NULL argument");
+    PCR_REQUIRE(P == 0 || (pair_p && pair_q), "pcr_reduce_pairs: NULL pair list");
+    PCR_HIP(hipSetDevice(ctx->device));
+    if (P == 0) {
+        memset(partials, 0, sizeof(double) * 17);
+        return PCR_OK;
+    }
+    const uint32_t nb = (P + 255) / 256;
+    double *buf = nullptr;  // [3P | 3P | 17*nb | 17]
+    const size_t n3 = (size_t)P * 3;
+    if (hipMalloc(&buf, sizeof(double) * (2 * n3 + 17 * (size_t)nb + 17)) != hipSuccess) {
+        set_last_error("pcr_reduce_pairs: device allocation for %u pairs failed", P);
+        return PCR_E_NOMEM;
+    }
+    StepArgs A;
+    memset(&A, 0, sizeof A);
+    memcpy(A.pivot_p, pivot_p, sizeof A.pivot_p);
+    memcpy(A.pivot_q, pivot_q, sizeof A.pivot_q);
+    A.block_partials = buf + 2 * n3;
+    double *res_d = A.block_partials + 17 * (size_t)nb;
+    hipError_t e = hipMemcpyAsync(buf, pair_p, sizeof(double) * n3, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(buf + n3, pair_q, sizeof(double) * n3, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(reduce_pairs_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const double *)buf,
+                           (const double *)(buf + n3), P, A);
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(17), dim3(256), 0, ctx->stream, (const double *)A.block_partials, nb,
+                           res_d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(partials, res_d, sizeof(double) * 17, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(buf);
     PCR_HIP(e);
     return PCR_OK;
 }

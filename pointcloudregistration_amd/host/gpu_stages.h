@@ -1,0 +1,148 @@
+// The MI355X plugins for the ICP fine-registration loop.  Each derives from the same stage base class and is
+// selected by the same config keys (F_CORRESPONDENCEESTIMATION, F_CORRESPONDENCEREJECTION,
+// F_TRANSFORMATIONESTIMATION, F_SAMPLER -- ICPConstGlobleValue.h:8-21) as the reference plugin it replaces:
+//
+//   CCorrespondenceEstimationClosestPointsGPU  <- CCorrespondenceEstimationClosestPoints
+//        (FineRegistrationClosestPoints/CorrespondenceEstimationClosestPoints.cpp:40-124)
+//   CCorrespondenceRejectionClosestPoints      <- same name, pass-through (CorrespondenceRejectionClosestPoints.cpp:18-22)
+//   CRejectionCentroidDistGPU                  <- CRejectionCentroidDist (RejectionCentroidDist.cpp:23-208)
+//   CTransformationEstimationSVD2GPU           <- CTransformationEstimationSVD2 (TransformationEstimationSVD2.cpp:17-117)
+//   CUniqueData                                <- CUniqueData (UniqueData.cpp:25-53), on the shared GPU index
+//   CSamplerIndexList                          deterministic sampler used by the harness
+//
+// All device work goes through the C ABI in include/pcr.h; nothing here touches HIP.
+#pragma once
+#include <string>
+#include <vector>
+#include "device_session.h"
+#include "stage_interfaces.h"
+
+namespace hiveRegistration {
+
+// What one fused ICP step leaves behind: the 17 partial sums (already summed over ranks) and everything needed
+// to materialise the pair lists later, if a host-side stage asks for them.
+struct SDeviceStepResult {
+    double Partials[17], PivotP[3], PivotQ[3];
+    Eigen::Matrix3d R;
+    ColVector3 T;
+    unsigned int K;
+    double ThrFwd, ThrRev;
+    const hivePointCloud::CPointCloud *pSource, *pTarget;
+    std::vector<unsigned int> SampleIdx;  // empty = every source point
+    bool Materialised;
+    VecColVector3 SrcPoints, SrcNormals, TgtPoints, TgtNormals;
+    SDeviceStepResult() : K(0), ThrFwd(0), ThrRev(0), pSource(NULL), pTarget(NULL), Materialised(false) {}
+    void materialise();  // re-runs the step with index outputs and gathers the kept pairs, in sample order
+};
+
+// One side of a CorrespondencePairSet whose points are still on the GPU.  getNumPoint() answers from the
+// partials; getPointSet()/getNormalSet() copy the pairs back on first use (CBasePointCloudSubset::_materializeV).
+class CDevicePairSubset : public CBasePointCloudSubset {
+public:
+    CDevicePairSubset(const std::shared_ptr<SDeviceStepResult> &vResult, bool vIsSourceSide)
+        : m_pResult(vResult), m_IsSourceSide(vIsSourceSide), m_Copied(false) {}
+    const SDeviceStepResult &getStepResult() const { return *m_pResult; }
+    virtual unsigned int getNumPoint() const { return (unsigned int)m_pResult->Partials[0]; }
+
+protected:
+    virtual ~CDevicePairSubset() {}
+    virtual void _materializeV() const;
+
+private:
+    std::shared_ptr<SDeviceStepResult> m_pResult;
+    bool m_IsSourceSide;
+    mutable bool m_Copied;
+};
+
+class CUniqueData : public hiveCommon::CBaseProduct {
+    PCR_FACTORY_CREATABLE(CUniqueData)
+public:
+    static std::string getSigSrcUniqueData() { return toUpperCopy("SrcUniqueData"); }
+    static std::string getSigTgtUniqueData() { return toUpperCopy("TgtUniqueData"); }
+    CUniqueData() : m_UnitSquareDist(0.0) { _letFactoryReleaseProduct(); }
+    void setPointCloud(const hivePointCloud::CPointCloud &vPointCloud);
+    double getUniqSquareDist() const { return m_UnitSquareDist; }
+    // no reference counterpart: lets a harness drive the host-only stages (criteria) without a device
+    void setUniqSquareDist(double vValue) { m_UnitSquareDist = vValue; }
+
+private:
+    double m_UnitSquareDist;
+};
+
+class CSamplerIndexList : public CBaseSampler {
+    PCR_FACTORY_CREATABLE(CSamplerIndexList)
+public:
+    CSamplerIndexList() { _letFactoryReleaseProduct(); }
+    static std::string getClassSig() { return toUpperCopy("SamplerIndexList"); }
+    // empty list = every point of the cloud, in index order
+    void setIndexList(const std::vector<unsigned int> &vIndexList) { m_IndexList = vIndexList; }
+
+protected:
+    virtual CorrespondencePointSet _doSampleV(const hivePointCloud::CPointCloud &vPointCloud);
+
+private:
+    std::vector<unsigned int> m_IndexList;
+};
+
+class CCorrespondenceEstimationClosestPointsGPU : public CBaseCorrespondenceEstimation {
+    PCR_FACTORY_CREATABLE(CCorrespondenceEstimationClosestPointsGPU)
+public:
+    CCorrespondenceEstimationClosestPointsGPU();
+    static std::string getClassSig() { return toUpperCopy("CorrespondenceEstimationClosestPointsGPU"); }
+    // the reference plugin's keys, so one RegCfg.txt drives either implementation
+    static std::string getKeyNumNeighbors() { return toUpperCopy("CorrespondenceEstimationClosestPoints.NN"); }
+    static std::string getKeySquareDistFactorThreshold() { return toUpperCopy("CorrespondenceEstimationClosestPoints.SDFT"); }
+    static std::string getKeyNeighbourDistFactorThreshold() { return toUpperCopy("CorrespondenceEstimationClosestPoints.NDFT"); }
+
+protected:
+    virtual ~CCorrespondenceEstimationClosestPointsGPU() {}
+    virtual void _setPointCloudV(const hivePointCloud::CPointCloud *vSourcePointCloud, const hivePointCloud::CPointCloud *vTargetPointCloud);
+    virtual void _determineCorrespondencesV(const CorrespondencePointSet &vSourceCorrespondencePointSet, const Eigen::Matrix3d &vR,
+                                            const ColVector3 &vT, CorrespondencePairSet &vioCorrespondencePairs);
+
+private:
+    unsigned int m_NumNeighbors;
+    double m_SquareDistFactorThreshold, m_NeighbourDistFactorThreshold;
+};
+
+class CCorrespondenceRejectionClosestPoints : public CBaseCorrespondenceRejection {
+    PCR_FACTORY_CREATABLE(CCorrespondenceRejectionClosestPoints)
+public:
+    CCorrespondenceRejectionClosestPoints() { _letFactoryReleaseProduct(); }
+    static std::string getClassSig() { return toUpperCopy("CorrespondenceRejectionClosestPoints"); }
+
+protected:
+    virtual void _rejectInvalidPairsV(const CorrespondencePairSet &vAll, CorrespondencePairSet &voValid) { voValid = vAll; }
+};
+
+class CRejectionCentroidDistGPU : public CBaseCorrespondenceRejection {
+    PCR_FACTORY_CREATABLE(CRejectionCentroidDistGPU)
+public:
+    CRejectionCentroidDistGPU() { _letFactoryReleaseProduct(); }
+    static std::string getClassSig() { return toUpperCopy("RejectionCentroidDistGPU"); }
+    static std::string getKeyMaxSearchNum() { return toUpperCopy("RejectionCentroidDist.MSN"); }
+    static std::string getKeyMaxSearchDist() { return toUpperCopy("RejectionCentroidDist.MSD"); }
+    static std::string getKeyCriticalDistFactor() { return toUpperCopy("RejectionCentroidDist.CDF"); }
+
+protected:
+    virtual void _rejectInvalidPairsV(const CorrespondencePairSet &vAllCorrespondencePairs, CorrespondencePairSet &voValidCorrespondencePairs);
+};
+
+class CTransformationEstimationSVD2GPU : public CBaseTransformationEstimation {
+    PCR_FACTORY_CREATABLE(CTransformationEstimationSVD2GPU)
+public:
+    CTransformationEstimationSVD2GPU() { _letFactoryReleaseProduct(); }
+    static std::string getClassSig() { return toUpperCopy("TransformationEstimationSVD2GPU"); }
+    // TransformationEstimationSVD2.cpp:33-49: increment (voR, voT) that maps point set A onto B
+    void computeRotationAndTranslation(const VecColVector3 &vPntSetA, const VecColVector3 &vPntSetB, Eigen::Matrix3d &voR, ColVector3 &voT);
+    using CBaseTransformationEstimation::computeRotationAndTranslation;
+
+protected:
+    virtual void _computeRotationAndTranslationV(const CorrespondencePairSet &vCorrespondencePairs, Eigen::Matrix3d &vioR, ColVector3 &vioT);
+};
+
+// Sum |p-q|^2 and pair count of a pair set without walking it when it is still on the device
+// (CDefaultConvergenceCriteria::__calculateMSE, DefaultConvergenceCriterial.cpp:46-65).  false if empty.
+bool pairSetMSE(const CorrespondencePairSet &vPairs, double &voMSE, unsigned int &voNumPairs);
+
+}  // namespace hiveRegistration
