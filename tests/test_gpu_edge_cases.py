@@ -1,0 +1,109 @@
+"""GPU edge cases of the K-NN / ICP-step entry points, through the C ABI: the inputs the reference's own code
+paths meet at their limits (tiny and degenerate clouds, K at its maximum and above the cloud size, exact ties,
+duplicates, queries far outside the bounds, non-finite coordinates, empty batches)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NO_INDEX = 0xFFFFFFFF
+
+
+def brute(X, Q, k):
+    """Exact K-NN under the library's documented total order (d2, index); d2 in the reference's operation order."""
+    d = ((Q[:, None, 0] - X[None, :, 0]) ** 2 + (Q[:, None, 1] - X[None, :, 1]) ** 2) + (Q[:, None, 2] - X[None, :, 2]) ** 2
+    idx = np.argsort(d, axis=1, kind="stable")[:, :k]  # stable: ties keep the lowest index first
+    return idx.astype(np.uint32), np.take_along_axis(d, idx, 1)
+
+
+@pytest.mark.parametrize("kind", ["grid", "brute"])
+def test_tiny_clouds_and_k_limits(pcr, ctx, kind):
+    kd = pcr.INDEX_GRID if kind == "grid" else pcr.INDEX_BRUTE
+    rng = np.random.default_rng(1)
+    for n in (1, 2, 3, 31, 32, 33):
+        X = rng.standard_normal((n, 3))
+        ix = pcr.Index(ctx, pcr.Cloud(ctx, X), kind=kd)
+        Q = rng.standard_normal((17, 3)) * 2
+        for k in sorted({1, min(n, 4), min(n, 32)}):
+            got, gd = ix.knn(Q, k, want_d2=True)
+            want, wd = brute(X, Q, k)
+            assert (got == want).all() and (gd == wd).all(), (n, k)
+        with pytest.raises(pcr.PcrError) as e:  # K > N: the reference reads past its result set; here an error
+            ix.knn(Q, n + 1)
+        assert e.value.status in (-1, -4)
+    X = rng.standard_normal((100, 3))
+    ix = pcr.Index(ctx, pcr.Cloud(ctx, X), kind=kd)
+    with pytest.raises(pcr.PcrError) as e:
+        ix.knn(X[:2], 33)  # above PCR_MAX_K
+    assert e.value.status == -4
+    with pytest.raises(pcr.PcrError):
+        ix.knn(X[:2], 0)
+    assert ix.knn(np.empty((0, 3)), 1).shape == (0, 1)  # empty batch: nothing to do, no error
+
+
+def test_exact_ties_and_duplicates_lowest_index(pcr, ctx):
+    """Lattice (every query has many exactly equidistant candidates) and repeated points: the library's
+    documented order (d2, index).  (The reference keeps the first candidate in KD-tree visiting order instead:
+    divergence class 8c-i, covered on the oracle side by tests/test_oracle.py.)"""
+    g = np.arange(12, dtype=np.float64)
+    X = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3) * 0.25
+    X = np.concatenate([X, X[:500], X[100:300]])  # duplicates of earlier points, higher indices
+    Q = np.concatenate([X[::7], X[::11] + 0.125])  # on lattice points and at cell centres (8-way ties)
+    for kind in (pcr.INDEX_GRID, pcr.INDEX_BRUTE):
+        ix = pcr.Index(ctx, pcr.Cloud(ctx, X), kind=kind)
+        for k in (1, 4, 8, 27):
+            got, gd = ix.knn(Q, k, want_d2=True)
+            want, wd = brute(X, Q, k)
+            assert (gd == wd).all() and (got == want).all(), k
+
+
+def test_degenerate_extents(pcr, ctx):
+    """All points identical, collinear, and coplanar clouds (zero-width bounding boxes; hiveSearch::CKNNSearch
+    recurses forever on > 10 identical points, NewKNNSearch.cpp:179-208 -- the grid must not care)."""
+    rng = np.random.default_rng(2)
+    same = np.tile([[1.5, -2.0, 3.0]], (50, 1))
+    line = np.zeros((400, 3))
+    line[:, 1] = rng.random(400)
+    plane = rng.random((3000, 3))
+    plane[:, 2] = 7.0
+    for X in (same, line, plane):
+        ix = pcr.Index(ctx, pcr.Cloud(ctx, X), kind=pcr.INDEX_GRID)
+        Q = np.concatenate([X[:20], X[:20] + [0.3, -0.2, 0.1]])
+        got, gd = ix.knn(Q, 4, want_d2=True)
+        want, wd = brute(X, Q, 4)
+        assert (got == want).all() and (gd == wd).all()
+
+
+def test_far_and_nonfinite_queries(pcr, ctx):
+    rng = np.random.default_rng(3)
+    X = rng.random((20000, 3))
+    ix = pcr.Index(ctx, pcr.Cloud(ctx, X), kind=pcr.INDEX_GRID)
+    Q = np.array([[1e6, -1e6, 3e5], [0.5, 0.5, 1e9], [-40.0, 0.2, 0.3], [0.5, 0.5, 0.5]])
+    got, gd = ix.knn(Q, 4, want_d2=True)
+    want, wd = brute(X, Q, 4)
+    assert (got == want).all() and (gd == wd).all()
+    Qn = np.array([[np.nan, 0.0, 0.0], [0.1, np.inf, 0.2], [0.5, 0.5, 0.5]])
+    got = ix.knn(Qn, 2)
+    assert (got[:2] == NO_INDEX).all()            # a non-finite query has no neighbours (and must not hang)
+    assert (got[2] == brute(X, Qn[2:], 2)[0][0]).all()
+    # bounded search: neighbours at d2 >= max_d2 are not reported
+    got, gd = ix.knn(Q[3:], 8, max_d2=float(wd[3, 2]), want_d2=True)
+    assert (got[0, :2] == want[3, :2]).all() and (got[0, 2:] == NO_INDEX).all() and np.isinf(gd[0, 2:]).all()
+
+
+def test_step_rejects_bad_arguments(pcr, ctx):
+    rng = np.random.default_rng(4)
+    X = rng.random((500, 3))
+    six, tix = pcr.Index(ctx, pcr.Cloud(ctx, X)), pcr.Index(ctx, pcr.Cloud(ctx, X + 0.01))
+    R, T = np.eye(3).reshape(9), np.zeros(3)
+    for bad in (dict(k=0), dict(k=501), dict(k=33)):
+        with pytest.raises(pcr.PcrError):
+            pcr.icp_step(ctx, six, tix, R, T, bad["k"], 1.0, 1.0)
+    with pytest.raises(pcr.PcrError):  # not a rotation
+        pcr.icp_step(ctx, six, tix, 2.0 * R, T, 1, 1.0, 1.0)
+    with pytest.raises(pcr.PcrError):
+        pcr.icp_step(ctx, six, tix, R, np.array([np.nan, 0, 0]), 1, 1.0, 1.0)
+    with pytest.raises(pcr.PcrError):  # sample index out of range
+        pcr.icp_step(ctx, six, tix, R, T, 1, 1.0, 1.0, sample_idx=np.array([0, 500], np.uint32))
+    out = pcr.icp_step(ctx, six, tix, R, T, 1, 1.0, 1.0, sample_idx=np.empty(0, np.uint32))
+    assert out["partials"][0] == 0  # empty sample set: zero sums, no error
