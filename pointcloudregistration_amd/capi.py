@@ -242,7 +242,7 @@ class Index:
 
 
 def icp_step(ctx, src_index, tgt_index, R, T, k, thr_fwd_sq, thr_rev_sq, sample_idx=None, exact=True,
-             want_outputs=True):
+             want_outputs=True, flags=0):
     R, T = _rt(R, T)
     if sample_idx is not None:
         sample_idx = np.ascontiguousarray(sample_idx, np.uint32)
@@ -254,13 +254,13 @@ def icp_step(ctx, src_index, tgt_index, R, T, k, thr_fwd_sq, thr_rev_sq, sample_
     rev = np.empty(m, np.uint32) if want_outputs else None
     keep = np.empty(m, np.uint8) if want_outputs else None
     _check(lib().pcr_icp_step(ctx.h, src_index.h, tgt_index.h, _u(sample_idx), m, _d(R), _d(T), k, thr_fwd_sq,
-                              thr_rev_sq, STEP_EXACT_INDICES if exact else 0, _d(partials), _u(fwd), _u(rev),
+                              thr_rev_sq, (STEP_EXACT_INDICES if exact else 0) | flags, _d(partials), _u(fwd), _u(rev),
                               _b(keep)), "pcr_icp_step")
     return dict(partials=partials, fwd=fwd, rev=rev, keep=keep)
 
 
 def icp_step_d(ctx, src_index, tgt_index, R, T, k, thr_fwd_sq, thr_rev_sq, partials_t, sample_begin=0, m=None,
-               sample_idx_t=None, exact=False, out_fwd_t=None, out_rev_t=None, out_keep_t=None):
+               sample_idx_t=None, exact=False, out_fwd_t=None, out_rev_t=None, out_keep_t=None, flags=0):
     """Asynchronous, device-resident step: partials_t is a float64 CUDA tensor of >= 17 elements."""
     R, T = _rt(R, T)
     if m is None:
@@ -270,7 +270,7 @@ def icp_step_d(ctx, src_index, tgt_index, R, T, k, thr_fwd_sq, thr_rev_sq, parti
         return _vp(t.data_ptr()) if t is not None else None
 
     _check(lib().pcr_icp_step_d(ctx.h, src_index.h, tgt_index.h, p(sample_idx_t), sample_begin, m, _d(R), _d(T), k,
-                                thr_fwd_sq, thr_rev_sq, STEP_EXACT_INDICES if exact else 0, p(partials_t),
+                                thr_fwd_sq, thr_rev_sq, (STEP_EXACT_INDICES if exact else 0) | flags, p(partials_t),
                                 p(out_fwd_t), p(out_rev_t), p(out_keep_t)), "pcr_icp_step_d")
 
 

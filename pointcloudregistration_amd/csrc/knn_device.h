@@ -11,6 +11,31 @@
 namespace pcr {
 
 #define PCR_INF __builtin_huge_val()
+#ifndef PCR_WALK_UNROLL
+#define PCR_WALK_UNROLL 3
+#endif
+
+#ifdef PCR_DIAG
+// diagnostic build only (libpcr_diag.so): counters of the lane search.  Never compiled into libpcr.so.
+static __device__ unsigned long long g_diag[16];
+#define DIAG_T() ((unsigned long long)__builtin_amdgcn_s_memtime())
+#define DIAG_ADD(slot, v)                                                                \
+    do {                                                                                 \
+        if ((int)(threadIdx.x & 63) == __ffsll((unsigned long long)__ballot(1)) - 1) atomicAdd(&g_diag[slot], (unsigned long long)(v)); \
+    } while (0)
+#else
+#define DIAG_T() 0ull
+#define DIAG_ADD(slot, v) \
+    do {                  \
+    } while (0)
+#endif
+#ifdef PCR_DIAG
+#define DIAG_LANE_ADD(slot, v) atomicAdd(&g_diag[slot], (unsigned long long)(v))
+#else
+#define DIAG_LANE_ADD(slot, v) \
+    do {                       \
+    } while (0)
+#endif
 
 // fp64 product and sum that the compiler may not fuse (the whole library is also built with
 // -ffp-contract=off; these keep the hot expressions safe if a flag is ever lost).
@@ -73,20 +98,21 @@ struct TopK {
         oi = ib;
     }
     // Insert (dist, i), keeping the slots sorted ascending by (d, idx); the caller has checked that the
-    // candidate beats slot KC-1.  Branch-free: b[j] = "candidate goes before slot j" is monotone in j, and
-    // slot j becomes slot j-1 (shift), the candidate, or stays.
+    // candidate beats slot KC-1.  The candidate replaces the worst slot and bubbles up by compare-exchange:
+    // one comparison and one conditional swap per slot, no second select level.
     __device__ __forceinline__ void insert(double dist, uint32_t i) {
-        bool b[KC];
-#pragma unroll
-        for (int j = 0; j < KC - 1; ++j) b[j] = better(dist, i, d[j], idx[j]);
-        b[KC - 1] = true;
+        d[KC - 1] = dist;
+        idx[KC - 1] = i;
 #pragma unroll
         for (int j = KC - 1; j >= 1; --j) {
-            d[j] = b[j - 1] ? d[j - 1] : (b[j] ? dist : d[j]);
-            idx[j] = b[j - 1] ? idx[j - 1] : (b[j] ? i : idx[j]);
+            const bool up = better(d[j], idx[j], d[j - 1], idx[j - 1]);
+            const double dl = up ? d[j] : d[j - 1], dh = up ? d[j - 1] : d[j];
+            const uint32_t il = up ? idx[j] : idx[j - 1], ih = up ? idx[j - 1] : idx[j];
+            d[j - 1] = dl;
+            d[j] = dh;
+            idx[j - 1] = il;
+            idx[j] = ih;
         }
-        d[0] = b[0] ? dist : d[0];
-        idx[0] = b[0] ? i : idx[0];
     }
 };
 
@@ -259,15 +285,20 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
 }
 
 
-// Ring 1 (the 3x3x3 cells around the query's own cell) straight from global memory, one lane per query,
-// with the same pruning as the tile scan: the nine (y,z) rows are visited centre first, and a row -- or
-// the outer cell of a row -- is skipped once its slab is provably farther than the current K-th best.
-// One loop with a straight-line body (open next row | evaluate one candidate), so the compiler emits a
-// single tight loop.  Returns true if the K-th best is provably final (or the grid is exhausted).
+// Ring 1 (the 3x3x3 cells around the query's own cell) straight from global memory, one lane per query.
+// The nine (y,z) rows are visited centre first, and a row -- or the outer cell of a row -- is skipped once its
+// slab is provably farther than the current K-th best.  What a row needs when it is opened (its slab distance
+// and the cell-table offset of its centre cell) is computed ONCE in straight-line code and parked in the lane's
+// column of a small LDS table; opening a row in the loop is then one LDS read, two compares and two cell-table
+// loads instead of ~90 instructions of decode and 64-bit address arithmetic.
+// One loop with a straight-line body (open next row | evaluate up to PCR_WALK_UNROLL candidates).
+// rowtab: this lane's column, row r at rowtab[r * PCR_ROW_STRIDE] (consecutive lanes, 8 bytes: conflict-free).
+// Returns true if the K-th best is provably final (or the grid is exhausted).
+#define PCR_ROW_STRIDE 256
 template <int KC>
 __device__ __forceinline__ bool ring1_pruned(const GridView &g, const Pt4 *__restrict__ cand, double qx, double qy,
                                              double qz, double sx, double sy, double sz, double max_d2,
-                                             double bound_scale, double extra_margin, TopK<KC> &top) {
+                                             double bound_scale, double extra_margin, TopK<KC> &top, uint2 *rowtab) {
     const uint32_t *__restrict__ cs = g.cs;
     const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
     const int cx = cell_coord(sx, g.lo[0], g.inv_h, gx);
@@ -294,39 +325,62 @@ __device__ __forceinline__ bool ring1_pruned(const GridView &g, const Pt4 *__res
     gl = gl > 0.0 ? gl : 0.0;
     gh = gh > 0.0 ? gh : 0.0;
     const double gzl = gl * gl * bound_scale, gzh = gh * gh * bound_scale;
-    // rows in order of increasing slab distance class: centre, 4 faces, 4 edges; (dy+1) | (dz+1) << 2
-    const unsigned long long order = 0x5ull | (0x4ull << 4) | (0x6ull << 8) | (0x1ull << 12) | (0x9ull << 16) |
-                                     (0x0ull << 20) | (0x2ull << 24) | (0x8ull << 28) | (0xaull << 32);
+    // row table, rows in order of increasing slab distance class: centre, 4 faces, 4 edges.  The slab distance is
+    // kept as a float rounded DOWN (a smaller bound only prunes less); rows outside the grid get +inf = never open.
+    // The cell table has <= 2^30 entries (pcr_index_params.max_cells), so its offsets fit 32 bits.
+    {
+        constexpr int DY[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
+        constexpr int DZ[9] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
+        const uint32_t cbase = ((uint32_t)cz * (uint32_t)gy + (uint32_t)cy) * (uint32_t)gx + (uint32_t)cx;
+        const int zstep = gx * gy;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const int ry = cy + DY[r], rz = cz + DZ[r];
+            const double gy2 = DY[r] < 0 ? gyl : (DY[r] > 0 ? gyh : 0.0);
+            const double gz2 = DZ[r] < 0 ? gzl : (DZ[r] > 0 ? gzh : 0.0);
+            const bool inside = (ry >= 0) & (ry < gy) & (rz >= 0) & (rz < gz);
+            const float f = inside ? __double2float_rd(gy2 + gz2) : __builtin_huge_valf();
+            rowtab[r * PCR_ROW_STRIDE] = make_uint2(__float_as_uint(f), cbase + (uint32_t)(DY[r] * gx + DZ[r] * zstep));
+        }
+    }
+    const bool has_xl = cx > 0, has_xh = cx < gx - 1;
     int ri = 0;
     uint32_t p = 0, e = 0;
     bool alive = true;
     while (alive) {
+        DIAG_ADD(8 * (KC == 1) + 0, 1);                                        // wave trips
+        DIAG_ADD(8 * (KC == 1) + 1, __any((p >= e) & (ri < 9)) ? 1 : 0);       // wave-level open executions
         if ((p >= e) & (ri < 9)) {
-            const int code = (int)(order >> (4 * ri)) & 15;
+            const uint2 row = rowtab[ri * PCR_ROW_STRIDE];
             ++ri;
-            const int dy = (code & 3) - 1, dz = (code >> 2) - 1;
-            const int ry = cy + dy, rz = cz + dz;
-            const double gy2 = dy < 0 ? gyl : (dy > 0 ? gyh : 0.0);
-            const double gz2 = dz < 0 ? gzl : (dz > 0 ? gzh : 0.0);
-            const double gyz = gy2 + gz2;
-            const bool open = (ry >= 0) & (ry < gy) & (rz >= 0) & (rz < gz) & !(wd < gyz);
-            if (open) {
-                const int xs = (cx > 0) & !(wd < gyz + gxl) ? cx - 1 : cx;
-                const int xe = (cx < gx - 1) & !(wd < gyz + gxh) ? cx + 1 : cx;
-                const size_t base = ((size_t)rz * gy + ry) * gx;
-                p = cs[base + xs];
-                e = cs[base + xe + 1];
+            const double gyz = (double)__uint_as_float(row.x);
+            // rows outside the grid carry +inf; the explicit test matters while wd itself is still +inf
+            if ((row.x != 0x7f800000u) & !(wd < gyz)) {
+                const uint32_t xs = has_xl & !(wd < gyz + gxl) ? row.y - 1u : row.y;
+                const uint32_t xe = has_xh & !(wd < gyz + gxh) ? row.y + 2u : row.y + 1u;
+                p = cs[xs];
+                e = cs[xe];
             }
         }
         if (p < e) {
-            const Pt4 c = cand[p];
-            ++p;
-            const double d = sqdist3(qx, qy, qz, c.x, c.y, c.z);
-            const uint32_t ci = (uint32_t)c.w;
-            if (better(d, ci, wd, wi)) {
-                top.insert(d, ci);
-                wd = top.worst_d();
-                wi = top.worst_i();
+            // PCR_WALK_UNROLL candidates per trip: their loads are in flight together, and the loop bookkeeping
+            // is paid once.  Slots past the end of the range re-read its last candidate and are ignored.
+            Pt4 c[PCR_WALK_UNROLL];
+            const uint32_t last = e - 1;
+#pragma unroll
+            for (int u = 0; u < PCR_WALK_UNROLL; ++u) c[u] = cand[min(p + (uint32_t)u, last)];
+            const uint32_t left = e - p;
+            p += min(left, (uint32_t)PCR_WALK_UNROLL);
+            DIAG_LANE_ADD(8 * (KC == 1) + 2, min(left, (uint32_t)PCR_WALK_UNROLL));
+#pragma unroll
+            for (int u = 0; u < PCR_WALK_UNROLL; ++u) {
+                const double d = sqdist3(qx, qy, qz, c[u].x, c[u].y, c[u].z);
+                const uint32_t ci = (uint32_t)c[u].w;
+                if (((uint32_t)u < left) & better(d, ci, wd, wi)) {
+                    top.insert(d, ci);
+                    wd = top.worst_d();
+                    wi = top.worst_i();
+                }
             }
         }
         alive = (p < e) | (ri < 9);
@@ -351,8 +405,12 @@ __device__ __forceinline__ bool ring1_pruned(const GridView &g, const Pt4 *__res
 template <int KC>
 __device__ __forceinline__ void lane_search(const GridView &g, const Pt4 *__restrict__ cand, double qx, double qy,
                                             double qz, double sx, double sy, double sz, double max_d2,
-                                            double bound_scale, double extra_margin, TopK<KC> &top) {
-    if (!ring1_pruned<KC>(g, cand, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top))
+                                            double bound_scale, double extra_margin, TopK<KC> &top,
+                                            uint2 *rowtab) {
+    DIAG_LANE_ADD(8 * (KC == 1) + 5, 1);  // lane searches
+    const bool fin1 = ring1_pruned<KC>(g, cand, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, rowtab);
+    DIAG_LANE_ADD(8 * (KC == 1) + 6, fin1 ? 0 : 1);  // lanes continuing with ring 2
+    if (!fin1)
         grid_search<KC>(g, cand, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, 2);
 }
 

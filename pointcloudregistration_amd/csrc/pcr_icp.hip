@@ -11,7 +11,7 @@
 // kernel folds the block partials in a fixed order (bitwise reproducible run to run).
 #include <math.h>
 #include <string.h>
-#include "tile_search.h"
+#include "knn_device.h"
 #ifndef PCR_STEP_WAVES
 #define PCR_STEP_WAVES 4
 #endif
@@ -41,7 +41,6 @@ struct StepArgs {
     int k;
     double thr_fwd, thr_rev;
     uint32_t exact;  // PCR_STEP_EXACT_INDICES
-    int halo0, per_lane;
     double rev_bound_scale, rev_extra_margin;
     double pivot_p[3], pivot_q[3];
     double *block_partials;  // [17][gridDim.x]
@@ -96,7 +95,7 @@ __device__ __forceinline__ void accumulate(double (&acc)[17], bool keep, double 
     acc[16] = keep ? dF : 0.0;
 }
 
-template <int KC, bool TILE>
+template <int KC>
 __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(StepArgs A) {
     const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t t = lb * 256u + threadIdx.x;
@@ -124,16 +123,10 @@ __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(Step
     const bool fin = live && isfinite(px) && isfinite(py) && isfinite(pz);
     TopK<KC> top;
     top.init(fmax_d2);
-    WaveTile *tile = nullptr;
-    if constexpr (TILE) {
-        __shared__ WaveTile tiles[4];
-        tile = &tiles[threadIdx.x >> 6];
-        tile_search<KC>(A.tgt, A.tgt.pts, fin, px, py, pz, px, py, pz, fmax_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
-                        *tile, false);
-    } else {
-        if (fin)
-            lane_search<KC>(A.tgt, A.tgt.pts, px, py, pz, px, py, pz, fmax_d2, 1.0 - 1.8189894035458565e-12, 0.0, top);
-    }
+    __shared__ uint2 rowtab[9][256];  // per-lane row table of the ring walk (knn_device.h)
+    uint2 *my_rows = &rowtab[0][threadIdx.x];
+    if (fin)
+        lane_search<KC>(A.tgt, A.tgt.pts, px, py, pz, px, py, pz, fmax_d2, 1.0 - 1.8189894035458565e-12, 0.0, top, my_rows);
     double dF;
     uint32_t j;
     top.slot(A.k, dF, j);  // NeighborSet.back() = K-th nearest (:91-92)
@@ -158,13 +151,8 @@ __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(Step
     rt.d[0] = dF;
     rt.idx[0] = orig;
     const bool rev_active = need_rev && isfinite(sx) && isfinite(sy) && isfinite(sz);
-    if constexpr (TILE) {
-        tile_search<1>(A.src, A.tsrc, rev_active, qx, qy, qz, sx, sy, sz, PCR_INF, A.rev_bound_scale,
-                       A.rev_extra_margin, rt, *tile, false);
-    } else {
-        if (rev_active)
-            lane_search<1>(A.src, A.tsrc, qx, qy, qz, sx, sy, sz, PCR_INF, A.rev_bound_scale, A.rev_extra_margin, rt);
-    }
+    if (rev_active)
+        lane_search<1>(A.src, A.tsrc, qx, qy, qz, sx, sy, sz, PCR_INF, A.rev_bound_scale, A.rev_extra_margin, rt, my_rows);
     uint32_t r = PCR_NO_INDEX;
     bool keep = false;
     if (need_rev) {
@@ -380,8 +368,6 @@ int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
     A.thr_fwd = thr_fwd_sq;
     A.thr_rev = thr_rev_sq;
     A.exact = (flags & PCR_STEP_EXACT_INDICES) ? 1u : 0u;
-    A.halo0 = g_tune[1] < 1 ? 1 : g_tune[1];
-    A.per_lane = g_tune[0];
     // |R v| >= sigma_min |v| with sigma_min^2 >= 1 - 3*defect (Gershgorin on R^T R)
     A.rev_bound_scale = (1.0 - 3.0 * defect) * (1.0 - 1.8189894035458565e-12);
     double scale = fabs(T[0]) + fabs(T[1]) + fabs(T[2]);
@@ -416,14 +402,12 @@ int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
         hipLaunchKernelGGL(transform_kernel, dim3(min(2048u, (src->n + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const Pt4 *)src->pts_d, src->n, A.M, src->tpts_d);
     }
-#define LAUNCH_STEP(KC)                                                                                           \
-    do {                                                                                                          \
-        if (src->kind == PCR_INDEX_GRID && g_tune[0] == 2)                                                        \
-            hipLaunchKernelGGL((icp_step_grid_kernel<KC, true>), dim3(nb), dim3(256), 0, ctx->stream, A);         \
-        else if (src->kind == PCR_INDEX_GRID)                                                                     \
-            hipLaunchKernelGGL((icp_step_grid_kernel<KC, false>), dim3(nb), dim3(256), 0, ctx->stream, A);        \
-        else                                                                                                      \
-            hipLaunchKernelGGL(icp_step_brute_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, A);                \
+#define LAUNCH_STEP(KC)                                                                                \
+    do {                                                                                               \
+        if (src->kind == PCR_INDEX_GRID)                                                               \
+            hipLaunchKernelGGL(icp_step_grid_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, A);      \
+        else                                                                                           \
+            hipLaunchKernelGGL(icp_step_brute_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, A);     \
     } while (0)
     {
         ProfScope ps(ctx, PCR_PROF_STEP);

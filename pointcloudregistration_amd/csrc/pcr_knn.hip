@@ -6,7 +6,7 @@
 // uniform grid, or -- for small clouds -- a tiled brute-force scan with LDS-staged tiles.
 #include <math.h>
 #include <vector>
-#include "tile_search.h"
+#include "knn_device.h"
 
 namespace pcr {
 
@@ -24,9 +24,9 @@ __device__ __forceinline__ void write_result(const TopK<KC> &top, int k, int ord
     }
 }
 
-// One lane per query; the 64 queries of a wave are staged/scanned together (wave_search.h).
+// One lane per query, pruned ring walk (knn_device.h).
 // order (nullable): processing order of the queries (by grid brick), results go to the query's own row.
-template <int KC, bool TILE>
+template <int KC>
 __global__ void __launch_bounds__(256) knn_grid_kernel(GridView g, const double *__restrict__ q,
                                                        const uint32_t *__restrict__ order, uint32_t nq, int k,
                                                        int order_out, double max_d2, uint32_t *__restrict__ out_idx,
@@ -43,14 +43,10 @@ __global__ void __launch_bounds__(256) knn_grid_kernel(GridView g, const double 
     const bool active = live && isfinite(qx) && isfinite(qy) && isfinite(qz);
     TopK<KC> top;
     top.init(max_d2);
-    if constexpr (TILE) {
-        __shared__ WaveTile tiles[4];
-        tile_search<KC>(g, g.pts, active, qx, qy, qz, qx, qy, qz, max_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
-                        tiles[threadIdx.x >> 6], false);
-    } else {
-        if (active)
-            lane_search<KC>(g, g.pts, qx, qy, qz, qx, qy, qz, max_d2, 1.0 - 1.8189894035458565e-12, 0.0, top);
-    }
+    __shared__ uint2 rowtab[9][256];
+    if (active)
+        lane_search<KC>(g, g.pts, qx, qy, qz, qx, qy, qz, max_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
+                        &rowtab[0][threadIdx.x]);
     if (live)
         write_result<KC>(top, k, order_out, max_d2, out_idx + (size_t)i * k, out_d2 ? out_d2 + (size_t)i * k : nullptr);
 }
@@ -95,12 +91,9 @@ template <int KC>
 static void launch_knn(pcr_ctx *ctx, const pcr_index *ix, const double *q_d, const uint32_t *qorder, uint32_t nq,
                        uint32_t k, int order, double max_d2, uint32_t *oi_d, double *od_d) {
     const uint32_t nb = (nq + 255) / 256;
-    if (ix->kind == PCR_INDEX_GRID && g_tune[0] == 2)
-        hipLaunchKernelGGL((knn_grid_kernel<KC, true>), dim3(nb), dim3(256), 0, ctx->stream, ix->view, q_d, qorder, nq,
-                           (int)k, order, max_d2, oi_d, od_d);
-    else if (ix->kind == PCR_INDEX_GRID)
-        hipLaunchKernelGGL((knn_grid_kernel<KC, false>), dim3(nb), dim3(256), 0, ctx->stream, ix->view, q_d, qorder, nq,
-                           (int)k, order, max_d2, oi_d, od_d);
+    if (ix->kind == PCR_INDEX_GRID)
+        hipLaunchKernelGGL(knn_grid_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, ix->view, q_d, qorder, nq, (int)k,
+                           order, max_d2, oi_d, od_d);
     else
         hipLaunchKernelGGL(knn_brute_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, ix->pts_d, ix->n, q_d, nq,
                            (int)k, order, max_d2, oi_d, od_d);
