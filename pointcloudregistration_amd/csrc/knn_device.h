@@ -106,7 +106,8 @@ struct TopK {
 #pragma unroll
         for (int j = KC - 1; j >= 1; --j) {
             const bool up = better(d[j], idx[j], d[j - 1], idx[j - 1]);
-            const double dl = up ? d[j] : d[j - 1], dh = up ? d[j - 1] : d[j];
+            // distances are finite or +inf, never NaN: min/max order them exactly (equal values: either way)
+            const double dl = fmin(d[j], d[j - 1]), dh = fmax(d[j], d[j - 1]);
             const uint32_t il = up ? idx[j] : idx[j - 1], ih = up ? idx[j - 1] : idx[j];
             d[j - 1] = dl;
             d[j] = dh;
@@ -314,16 +315,19 @@ __device__ __forceinline__ bool ring1_pruned(const GridView &g, const Pt4 *__res
     gh = (g.lo[0] + (double)(cx + 1) * g.h) - sx - margin;
     gl = gl > 0.0 ? gl : 0.0;
     gh = gh > 0.0 ? gh : 0.0;
+    const double fxl = gl, fxh = gh;
     const double gxl = gl * gl * bound_scale, gxh = gh * gh * bound_scale;
     gl = sy - (g.lo[1] + (double)cy * g.h) - margin;
     gh = (g.lo[1] + (double)(cy + 1) * g.h) - sy - margin;
     gl = gl > 0.0 ? gl : 0.0;
     gh = gh > 0.0 ? gh : 0.0;
+    const double fyl = gl, fyh = gh;
     const double gyl = gl * gl * bound_scale, gyh = gh * gh * bound_scale;
     gl = sz - (g.lo[2] + (double)cz * g.h) - margin;
     gh = (g.lo[2] + (double)(cz + 1) * g.h) - sz - margin;
     gl = gl > 0.0 ? gl : 0.0;
     gh = gh > 0.0 ? gh : 0.0;
+    const double fzl = gl, fzh = gh;
     const double gzl = gl * gl * bound_scale, gzh = gh * gh * bound_scale;
     // row table, rows in order of increasing slab distance class: centre, 4 faces, 4 edges.  The slab distance is
     // kept as a float rounded DOWN (a smaller bound only prunes less); rows outside the grid get +inf = never open.
@@ -385,19 +389,18 @@ __device__ __forceinline__ bool ring1_pruned(const GridView &g, const Pt4 *__res
         }
         alive = (p < e) | (ri < 9);
     }
-    const int lx0 = max(cx - 1, 0), lx1 = min(cx + 1, gx - 1);
-    const int ly0 = max(cy - 1, 0), ly1 = min(cy + 1, gy - 1);
-    const int lz0 = max(cz - 1, 0), lz1 = min(cz + 1, gz - 1);
-    const bool all = (lx0 == 0) & (lx1 == gx - 1) & (ly0 == 0) & (ly1 == gy - 1) & (lz0 == 0) & (lz1 == gz - 1);
-    if (all) return true;
-    double ox = fmax(fmax(g.lo[0] - sx, sx - g.hi[0]), 0.0) - margin;
-    double oy = fmax(fmax(g.lo[1] - sy, sy - g.hi[1]), 0.0) - margin;
-    double oz = fmax(fmax(g.lo[2] - sz, sz - g.hi[2]), 0.0) - margin;
-    ox = ox > 0.0 ? ox : 0.0;
-    oy = oy > 0.0 ? oy : 0.0;
-    oz = oz > 0.0 ? oz : 0.0;
-    const double b2 =
-        box_bound2(g, sx, sy, sz, margin, ox * ox, oy * oy, oz * oz, lx0, lx1, ly0, ly1, lz0, lz1) * bound_scale;
+    // Is the K-th best final?  An unvisited point is either in a pruned row/cell (farther than the bound that
+    // pruned it, which was >= the final wd) or outside the 3x3x3 box, i.e. beyond a box face: at least one whole
+    // cell plus the (margin-shrunk, clamped) gap to the own cell's face away along that axis.  Faces on the grid
+    // boundary have nothing beyond them.
+    double b2 = PCR_INF;
+    if (cx > 1) b2 = fmin(b2, (fxl + g.h) * (fxl + g.h));
+    if (cx < gx - 2) b2 = fmin(b2, (fxh + g.h) * (fxh + g.h));
+    if (cy > 1) b2 = fmin(b2, (fyl + g.h) * (fyl + g.h));
+    if (cy < gy - 2) b2 = fmin(b2, (fyh + g.h) * (fyh + g.h));
+    if (cz > 1) b2 = fmin(b2, (fzl + g.h) * (fzl + g.h));
+    if (cz < gz - 2) b2 = fmin(b2, (fzh + g.h) * (fzh + g.h));
+    b2 *= bound_scale * (1.0 - 4.440892098500626e-16);
     return (wd < b2) | (max_d2 <= b2);
 }
 

@@ -410,6 +410,121 @@ int brick_order(pcr_ctx *ctx, const GridView &g, const Pt4 *pts, const double *x
     return PCR_OK;
 }
 
+// ------------------------------------------------------------------ coarse ordering of a query batch
+// Queries arrive in arbitrary order; the search wants the 64 lanes of a wave to be neighbours in space.  A full
+// sort is not needed for that -- a counting sort by the TOP bits of a 30-bit Morton key (a few hundred queries
+// per bucket) is enough, and it can be done without a single scattered global atomic: every block histograms its
+// tile in LDS, reserves its share of each bucket with one coalesced returning atomic per touched bucket, and a
+// second kernel rebuilds the bucket starts in LDS and scatters with LDS atomics.  Not deterministic inside a
+// bucket, which no K-NN result depends on (every query's answer goes to its own row).
+constexpr int QS_TILE = 4096;        // queries per block
+constexpr int QS_THREADS = 1024;
+constexpr int QS_MAX_BUCKETS = 8192;  // 32 KiB of LDS
+
+struct QSortGeom {
+    double lo[3], scale;  // (v - lo) * scale -> [0, 1024)
+    int shift;            // key = morton30 >> shift
+    uint32_t buckets;
+};
+
+__device__ __forceinline__ uint32_t qsort_key(const QSortGeom &Q, const double *__restrict__ q, uint32_t i) {
+    double tx = (q[(size_t)i * 3] - Q.lo[0]) * Q.scale, ty = (q[(size_t)i * 3 + 1] - Q.lo[1]) * Q.scale,
+           tz = (q[(size_t)i * 3 + 2] - Q.lo[2]) * Q.scale;
+    tx = tx > 0.0 ? tx : 0.0;  // NaN -> 0: such queries are masked by the search itself
+    ty = ty > 0.0 ? ty : 0.0;
+    tz = tz > 0.0 ? tz : 0.0;
+    tx = tx > 1023.0 ? 1023.0 : tx;
+    ty = ty > 1023.0 ? 1023.0 : ty;
+    tz = tz > 1023.0 ? 1023.0 : tz;
+    const uint32_t m = spread3((uint32_t)tx) | (spread3((uint32_t)ty) << 1) | (spread3((uint32_t)tz) << 2);
+    return m >> Q.shift;
+}
+
+__global__ void __launch_bounds__(QS_THREADS) qsort_hist_kernel(const double *__restrict__ q, uint32_t nq, QSortGeom Q,
+                                                         uint16_t *__restrict__ keys, uint32_t *__restrict__ totals,
+                                                         uint32_t *__restrict__ basemat) {
+    __shared__ uint32_t hist[QS_MAX_BUCKETS];
+    for (uint32_t b = threadIdx.x; b < Q.buckets; b += QS_THREADS) hist[b] = 0;
+    __syncthreads();
+    const uint32_t first = blockIdx.x * QS_TILE;
+    const uint32_t last = min(first + (uint32_t)QS_TILE, nq);
+    for (uint32_t i = first + threadIdx.x; i < last; i += QS_THREADS) {
+        const uint32_t k = qsort_key(Q, q, i);
+        keys[i] = (uint16_t)k;
+        atomicAdd(&hist[k], 1u);
+    }
+    __syncthreads();
+    uint32_t *row = basemat + (size_t)blockIdx.x * Q.buckets;
+    for (uint32_t b = threadIdx.x; b < Q.buckets; b += QS_THREADS) {
+        const uint32_t c = hist[b];
+        row[b] = c ? atomicAdd(&totals[b], c) : 0u;  // consecutive lanes, consecutive buckets
+    }
+}
+
+__global__ void __launch_bounds__(QS_THREADS) qsort_scatter_kernel(const uint16_t *__restrict__ keys, uint32_t nq, QSortGeom Q,
+                                                            const uint32_t *__restrict__ totals,
+                                                            const uint32_t *__restrict__ basemat,
+                                                            uint32_t *__restrict__ order) {
+    __shared__ uint32_t cur[QS_MAX_BUCKETS];
+    __shared__ uint32_t part[QS_THREADS];
+    // exclusive scan of the bucket totals: each thread owns a contiguous run of buckets
+    const uint32_t per = (Q.buckets + QS_THREADS - 1) / QS_THREADS;
+    const uint32_t b0 = threadIdx.x * per, b1 = min(b0 + per, Q.buckets);
+    uint32_t sum = 0;
+    for (uint32_t b = b0; b < b1; ++b) sum += totals[b];
+    // block-wide exclusive scan of the per-thread sums: shuffles inside a wave, then the 16 wave totals
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) part[wave] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0;
+    for (int w = 0; w < wave; ++w) wave_base += part[w];
+    __syncthreads();
+    part[threadIdx.x] = wave_base + incl - sum;
+    __syncthreads();
+    const uint32_t *row = basemat + (size_t)blockIdx.x * Q.buckets;
+    uint32_t run = part[threadIdx.x];
+    for (uint32_t b = b0; b < b1; ++b) {
+        cur[b] = run + row[b];
+        run += totals[b];
+    }
+    __syncthreads();
+    const uint32_t first = blockIdx.x * QS_TILE;
+    const uint32_t last = min(first + (uint32_t)QS_TILE, nq);
+    for (uint32_t i = first + threadIdx.x; i < last; i += QS_THREADS) order[atomicAdd(&cur[keys[i]], 1u)] = i;
+}
+
+int coarse_query_order(pcr_ctx *ctx, const GridView &g, const double *q_d, uint32_t nq, uint32_t *order_d) {
+    QSortGeom Q;
+    double ext = 0;
+    for (int a = 0; a < 3; ++a) {
+        Q.lo[a] = g.lo[a];
+        ext = fmax(ext, g.hi[a] - g.lo[a]);
+    }
+    Q.scale = ext > 0 ? 1024.0 / ext : 0.0;
+    // aim at ~192 queries per bucket; points on a surface fill only a fraction of the Morton cube, so be generous
+    int bits = 6;
+    while (bits < 13 && ((uint64_t)192 << bits) < (uint64_t)nq * 2) ++bits;
+    Q.shift = 30 - bits;
+    Q.buckets = 1u << bits;
+    const uint32_t nblk = (nq + QS_TILE - 1) / QS_TILE;
+    uint16_t *keys = (uint16_t *)ctx_scratch(ctx, 0, sizeof(uint16_t) * (size_t)nq);
+    uint32_t *totals = (uint32_t *)ctx_scratch(ctx, 1, sizeof(uint32_t) * Q.buckets);
+    uint32_t *basemat = (uint32_t *)ctx_scratch(ctx, 2, sizeof(uint32_t) * (size_t)nblk * Q.buckets);
+    if (!keys || !totals || !basemat) return PCR_E_NOMEM;
+    PCR_HIP(hipMemsetAsync(totals, 0, sizeof(uint32_t) * Q.buckets, ctx->stream));
+    hipLaunchKernelGGL(qsort_hist_kernel, dim3(nblk), dim3(QS_THREADS), 0, ctx->stream, q_d, nq, Q, keys, totals, basemat);
+    hipLaunchKernelGGL(qsort_scatter_kernel, dim3(nblk), dim3(QS_THREADS), 0, ctx->stream, (const uint16_t *)keys, nq, Q,
+                       (const uint32_t *)totals, (const uint32_t *)basemat, order_d);
+    PCR_HIP(hipGetLastError());
+    return PCR_OK;
+}
+
 }  // namespace pcr
 
 using namespace pcr;

@@ -112,6 +112,8 @@ void *ctx_scratch(pcr_ctx *ctx, int slot, size_t bytes);
 // pts / xyz_aos is non-NULL.  deterministic: order inside a brick made ascending (index build only).
 int brick_order(pcr_ctx *ctx, const GridView &g, const Pt4 *pts, const double *xyz_aos, uint32_t n,
                 uint32_t *order_d, bool deterministic);
+// positions [0,nq) of a query batch grouped by the top bits of a Morton key (fast, not deterministic inside a group)
+int coarse_query_order(pcr_ctx *ctx, const GridView &g, const double *q_d, uint32_t nq, uint32_t *order_d);
 }  // namespace pcr
 
 struct pcr_cloud {

@@ -123,10 +123,10 @@ int pcr_knn_d(pcr_ctx *ctx, const pcr_index *ix, const double *q_d, uint32_t nq,
     // Order the queries by grid brick so that each wave's 64 queries share a small box (the callers'
     // query order is arbitrary); a handful of queries is not worth the extra launches.
     const uint32_t *qorder = nullptr;
-    if (ix->kind == PCR_INDEX_GRID && nq >= 2048) {
+    if (ix->kind == PCR_INDEX_GRID && nq >= 2048 && g_tune[3] == 0) {
         uint32_t *o = (uint32_t *)ctx_scratch(ctx, 4, sizeof(uint32_t) * (size_t)nq);
         if (!o) return PCR_E_NOMEM;
-        int rc = brick_order(ctx, ix->view, nullptr, q_d, nq, o, false);
+        int rc = coarse_query_order(ctx, ix->view, q_d, nq, o);
         if (rc != PCR_OK) return rc;
         qorder = o;
     }
