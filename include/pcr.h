@@ -194,6 +194,50 @@ int pcr_icp_pivots(const pcr_index *src_index, const pcr_index *tgt_index, const
 int pcr_reduce_pairs(pcr_ctx *ctx, const double *pair_p, const double *pair_q, uint32_t P, const double pivot_p[3],
                      const double pivot_q[3], double partials[17]);
 
+/* ---- the whole fit loop, device-resident -----------------------------------------------------
+ * Replaces CIterativeFit::__fitLoop / _fitStepV (IterativeFit.cpp:119-175) with its stages fused as above AND the
+ * 3x3 solve (TransformationEstimationSVD2.cpp:98-117), the composition (BaseTransformationEstimation.h:28-32) and
+ * CDefaultConvergenceCriteria::_isConvergedV (DefaultConvergenceCriterial.cpp:69-207) run by a one-thread kernel,
+ * so that (R,T) never leaves the device between iterations: a caller enqueues
+ *       pcr_fit_enqueue_step;  [all-reduce pcr_fit_partials_d in place on the same stream];  pcr_fit_enqueue_solve
+ * as many times as it allows iterations and reads the result once.  After the criteria report convergence (or no
+ * pair survives) every kernel still in the queue returns immediately.  The transforms are bit-identical to the
+ * host path (pcr_icp_step_d + pcr_solve_rigid): same source compiled for both.
+ * conv NULL: never converges by itself (a fixed number of iterations, e.g. for benchmarking).
+ * traj_cap: rows of the device-side trajectory log, each {R[9], T[3], mse, pairs} (0: none). */
+typedef struct {
+    uint32_t max_iterations;           /* BaseConvergenceCriteria.MI   (BaseConvergenceCriteria.cpp:20-27,33)   */
+    int failure_after_max_iterations;  /* DefaultConvergenceCriteria.FAMI (DefaultConvergenceCriterial.cpp:86-99) */
+    double rotation_threshold;         /* .RT  on |R_prev - R|_F^2            (:103-133)                         */
+    double translation_threshold;      /* .TT  on |T|^2, T accumulated        (:106)                             */
+    double abs_mse;                    /* .AMSE, scaled by the target's unit square distance (:137-170)          */
+    double rel_mse;                    /* .RMSE, likewise                     (:174-207)                         */
+    uint32_t max_similar;              /* .MIST                               (:111-123)                         */
+} pcr_convergence_params;
+typedef enum {                         /* EConvergenceState (DefaultConvergenceCriterial.h:32-40) */
+    PCR_FIT_NOT_CONVERGED = 0,
+    PCR_FIT_ITERATIONS = 1,
+    PCR_FIT_TRANSFORM = 2,
+    PCR_FIT_ABS_MSE = 3,
+    PCR_FIT_REL_MSE = 4,
+    PCR_FIT_NO_CORRESPONDENCES = 5,
+    PCR_FIT_DEGENERATE = -2            /* the accumulated R stopped being a rotation (no reference counterpart) */
+} pcr_fit_state;
+typedef struct pcr_fit pcr_fit;
+int pcr_fit_create(pcr_ctx *ctx, const pcr_index *src_index, const pcr_index *tgt_index,
+                   const uint32_t *sample_idx_d /*nullable*/, uint32_t sample_begin, uint32_t m, uint32_t k,
+                   double thr_fwd_sq, double thr_rev_sq, const pcr_convergence_params *conv /*nullable*/,
+                   double unique_sq_dist, uint32_t traj_cap, pcr_fit **out);
+/* (re)start from the initial transform: iteration 0, criteria state as freshly constructed */
+int pcr_fit_reset(pcr_fit *fit, const double R[9], const double T[3]);
+int pcr_fit_enqueue_step(pcr_fit *fit);
+double *pcr_fit_partials_d(pcr_fit *fit);
+int pcr_fit_enqueue_solve(pcr_fit *fit);
+/* synchronises the stream.  All outputs nullable; traj receives min(iterations, traj_cap, traj_rows) rows. */
+int pcr_fit_read(pcr_fit *fit, double R[9], double T[3], uint32_t *iterations, int *state, double *mse,
+                 double *pairs, double *traj, uint32_t traj_rows);
+int pcr_fit_destroy(pcr_fit *fit);
+
 /* ---- host: CTransformationEstimationSVD2::__computeRelativeRotationAndTranslation
  *      (TransformationEstimationSVD2.cpp:98-117) + accumulateTransformation
  *      (BaseTransformationEstimation.h:28-32), fed by the 17 partials instead of pair lists.

@@ -6,6 +6,7 @@ resolves to the HIP runtime torch already loaded, so device pointers and streams
 between torch tensors and this library (one runtime per process).
 """
 import ctypes as C
+import weakref
 import os
 
 import numpy as np
@@ -71,6 +72,14 @@ SYMBOLS = {
     "pcr_icp_step_d": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _dp, _dp, C.c_uint32, C.c_double,
                                  C.c_double, C.c_uint32, _vp, _vp, _vp, _vp]),
     "pcr_icp_pivots": (C.c_int, [_vp, _vp, _dp, _dp, _dp, _dp]),
+    "pcr_fit_create": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, _vp,
+                                 C.c_double, C.c_uint32, C.POINTER(_vp)]),
+    "pcr_fit_reset": (C.c_int, [_vp, _dp, _dp]),
+    "pcr_fit_enqueue_step": (C.c_int, [_vp]),
+    "pcr_fit_partials_d": (_vp, [_vp]),
+    "pcr_fit_enqueue_solve": (C.c_int, [_vp]),
+    "pcr_fit_read": (C.c_int, [_vp, _dp, _dp, _up, C.POINTER(C.c_int), _dp, _dp, _dp, C.c_uint32]),
+    "pcr_fit_destroy": (C.c_int, [_vp]),
     "pcr_reduce_pairs": (C.c_int, [_vp, _dp, _dp, C.c_uint32, _dp, _dp, _dp]),
     "pcr_solve_rigid": (C.c_int, [_dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "pcr_reject_centroid_dist": (C.c_int, [_vp, _vp, _vp, _dp, _dp, C.c_uint32, C.c_uint32, C.c_double, C.c_double,
@@ -132,6 +141,7 @@ class Context:
         self.h = _vp()
         _check(lib().pcr_ctx_create(device, C.byref(self.h)), "pcr_ctx_create")
         self.device = device
+        self._children = weakref.WeakSet()  # fits, indices, clouds: destroyed before the context they point into
         if stream is not None:
             _check(lib().pcr_ctx_set_stream(self.h, _vp(stream.cuda_stream)), "pcr_ctx_set_stream")
 
@@ -150,6 +160,9 @@ class Context:
 
     def close(self):
         if self.h:
+            for cls in (Fit, Index, Cloud):  # dependants first, in dependency order
+                for child in [c for c in self._children if isinstance(c, cls)]:
+                    child.close()
             lib().pcr_ctx_destroy(self.h)
             self.h = _vp()
 
@@ -167,6 +180,7 @@ class Cloud:
     def __init__(self, ctx, xyz):
         self.ctx = ctx
         self.h = _vp()
+        ctx._children.add(self)
         if isinstance(xyz, torch.Tensor):
             assert xyz.is_cuda and xyz.dtype == torch.float64 and xyz.is_contiguous()
             self._keep = xyz
@@ -201,6 +215,7 @@ class Index:
                  brute_max_points=0):
         self.ctx, self.cloud = ctx, cloud
         self.h = _vp()
+        ctx._children.add(self)
         prm = IndexParams(kind, target_occupancy, cell_size, max_cells, brute_max_points)
         _check(lib().pcr_index_build(ctx.h, cloud.h, C.byref(prm), C.byref(self.h)), "pcr_index_build")
         self.n = cloud.n
@@ -279,6 +294,90 @@ def icp_pivots(src_index, tgt_index, R, T):
     pp, pq = np.empty(3), np.empty(3)
     _check(lib().pcr_icp_pivots(src_index.h, tgt_index.h, _d(R), _d(T), _d(pp), _d(pq)), "pcr_icp_pivots")
     return pp, pq
+
+
+class ConvergenceParams(C.Structure):
+    """pcr_convergence_params; regcfg() = RegCfg.txt:5-11 over the defaults of DefaultConvergenceCriterial.cpp:28-33."""
+    _fields_ = [("max_iterations", C.c_uint32), ("failure_after_max_iterations", C.c_int),
+                ("rotation_threshold", C.c_double), ("translation_threshold", C.c_double),
+                ("abs_mse", C.c_double), ("rel_mse", C.c_double), ("max_similar", C.c_uint32)]
+
+    @classmethod
+    def regcfg(cls, max_iterations=30):
+        return cls(max_iterations, 0, 1e-6, 1e-7, 0.01, 0.01, 0)
+
+
+FIT_STATES = {0: "NotConverged", 1: "Criteria_Iterations", 2: "Criteria_Transform", 3: "Criteria_AbsMSE",
+              4: "Criteria_RelMSE", 5: "Criteria_NoCorrespondeces", -2: "Degenerate"}
+
+
+class Fit:
+    """pcr_fit: the device-resident loop.  step() and solve() only enqueue; read() synchronises."""
+
+    def __init__(self, ctx, src_index, tgt_index, k, thr_fwd_sq, thr_rev_sq, conv=None, unique_sq_dist=0.0,
+                 sample_idx_t=None, sample_begin=0, m=None, traj_cap=64):
+        self.ctx, self.src, self.tgt = ctx, src_index, tgt_index
+        self._keep = sample_idx_t
+        ctx._children.add(self)
+        if m is None:
+            m = sample_idx_t.numel() if sample_idx_t is not None else src_index.n - sample_begin
+        self.traj_cap = traj_cap
+        self.h = _vp()
+        _check(lib().pcr_fit_create(ctx.h, src_index.h, tgt_index.h,
+                                    _vp(sample_idx_t.data_ptr()) if sample_idx_t is not None else None, sample_begin, m, k,
+                                    thr_fwd_sq, thr_rev_sq, C.cast(C.byref(conv), _vp) if conv is not None else None,
+                                    unique_sq_dist, traj_cap, C.byref(self.h)), "pcr_fit_create")
+
+    def reset(self, R, T):
+        R, T = _rt(R, T)
+        _check(lib().pcr_fit_reset(self.h, _d(R), _d(T)), "pcr_fit_reset")
+
+    def step(self):
+        _check(lib().pcr_fit_enqueue_step(self.h), "pcr_fit_enqueue_step")
+
+    def solve(self):
+        _check(lib().pcr_fit_enqueue_solve(self.h), "pcr_fit_enqueue_solve")
+
+    def partials_tensor(self):
+        """The 17 partial sums as a torch view of the fit's device buffer (for torch.distributed.all_reduce)."""
+        import torch
+        ptr = lib().pcr_fit_partials_d(self.h)
+
+        class _Mem:
+            __cuda_array_interface__ = {"shape": (17,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(_Mem(), device=f"cuda:{self.ctx.device}")
+
+    def read(self):
+        R, T = np.empty(9), np.empty(3)
+        it, st = C.c_uint32(0), C.c_int(0)
+        mse, pairs = C.c_double(0), C.c_double(0)
+        traj = np.zeros((max(self.traj_cap, 1), 14))
+        _check(lib().pcr_fit_read(self.h, _d(R), _d(T), C.byref(it), C.byref(st), C.cast(C.byref(mse), _dp),
+                                  C.cast(C.byref(pairs), _dp), _d(traj), self.traj_cap), "pcr_fit_read")
+        return dict(R=R, T=T, iterations=it.value, state=st.value, msg=FIT_STATES.get(st.value, "?"), mse=mse.value,
+                    pairs=pairs.value, traj=traj[:min(it.value, self.traj_cap)])
+
+    def run(self, R, T, max_steps, all_reduce=None):
+        """Enqueue up to max_steps iterations from (R,T) and read the result (one synchronisation)."""
+        self.reset(R, T)
+        part = self.partials_tensor() if all_reduce is not None else None
+        for _ in range(max_steps):
+            self.step()
+            if all_reduce is not None:
+                all_reduce(part)
+            self.solve()
+        return self.read()
+
+    def close(self):
+        if self.h:
+            lib().pcr_fit_destroy(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def reduce_pairs(ctx, pair_p, pair_q, pivot_p=None, pivot_q=None):

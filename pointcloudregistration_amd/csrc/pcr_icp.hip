@@ -12,14 +12,56 @@
 #include <math.h>
 #include <string.h>
 #include "knn_device.h"
+#include "solve_core.h"
 #ifndef PCR_STEP_WAVES
 #define PCR_STEP_WAVES 4
 #endif
 
 namespace pcr {
 
-__global__ void __launch_bounds__(256) transform_kernel(const Pt4 *__restrict__ in, uint32_t n, Rigid M,
-                                                        Pt4 *__restrict__ out) {
+// What changes from one iteration to the next.  It lives in DEVICE memory: written by set_dyn_kernel (single-step
+// entry points: the host computed it) or by fit_solve_kernel (device-resident loop: the previous iteration's
+// solve computed it), read -- as wave-uniform scalars -- by the transform and step kernels.  No kernel argument
+// depends on the iteration, so a whole fit can be enqueued without the host ever waiting for the device.
+struct StepDyn {
+    Rigid M;         // current (R,T)
+    double rinv[9];  // inverse of R (column-major), for locating q in the source grid
+    double pivot_p[3], pivot_q[3];
+    double rev_bound_scale, rev_extra_margin;
+    uint32_t done;  // device-resident loop only: converged/stopped -- the remaining enqueued kernels return at once
+    uint32_t pad;
+};
+
+// (R,T) -> everything else in StepDyn.  Host and device run this same code (bit-identical results).
+//   c_src, c_tgt : centres of the clouds' bounds (the pivots only condition the sums)
+//   cloud_scale  : largest |coordinate| of either cloud
+// false: R is not a rotation to within 1e-3.
+PCR_HD inline bool make_dyn(const double *R, const double *T, const double *c_src, const double *c_tgt,
+                            double cloud_scale, StepDyn &D, double *defect_out) {
+    for (int i = 0; i < 9; ++i) D.M.r[i] = R[i];
+    for (int i = 0; i < 3; ++i) D.M.t[i] = T[i];
+    double defect = 0;
+    const bool ok = invert3(R, D.rinv, defect) && defect <= 1e-3;
+    if (defect_out) *defect_out = defect;
+    for (int r = 0; r < 3; ++r) {
+        D.pivot_p[r] = R[r] * c_src[0] + R[3 + r] * c_src[1] + R[6 + r] * c_src[2] + T[r];
+        D.pivot_q[r] = c_tgt[r];
+    }
+    // |R v| >= sigma_min |v| with sigma_min^2 >= 1 - 3*defect (Gershgorin on R^T R)
+    D.rev_bound_scale = (1.0 - 3.0 * defect) * (1.0 - 1.8189894035458565e-12);
+    const double scale = fmax(fabs(T[0]) + fabs(T[1]) + fabs(T[2]), 0.0) + cloud_scale;
+    D.rev_extra_margin = 3.637978807091713e-12 * scale;  // 2^-38: rounding of the inverse map
+    D.done = 0;
+    D.pad = 0;
+    return ok;
+}
+
+__global__ void set_dyn_kernel(StepDyn value, StepDyn *dst) { *dst = value; }
+
+__global__ void __launch_bounds__(256) transform_kernel(const Pt4 *__restrict__ in, uint32_t n,
+                                                        const StepDyn *__restrict__ dyn, Pt4 *__restrict__ out) {
+    if (dyn->done) return;
+    const Rigid M = dyn->M;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const Pt4 s = in[i];
         Pt4 o;
@@ -36,13 +78,10 @@ struct StepArgs {
     const uint32_t *src_order;   // positions of src.pts in brick order (processing order of "all samples")
     const uint32_t *sample_idx;  // NULL: samples are positions [sample_begin, sample_begin+m)
     uint32_t sample_begin, m;
-    Rigid M;         // current (R,T)
-    double rinv[9];  // inverse of R (column-major), for locating q in the source grid
+    const StepDyn *dyn;          // per-iteration values (device memory)
     int k;
     double thr_fwd, thr_rev;
     uint32_t exact;  // PCR_STEP_EXACT_INDICES
-    double rev_bound_scale, rev_extra_margin;
-    double pivot_p[3], pivot_q[3];
     double *block_partials;  // [17][gridDim.x]
     uint32_t *out_fwd, *out_rev;
     uint8_t *out_keep;
@@ -72,7 +111,7 @@ __device__ __forceinline__ void block_reduce17(double (&v)[17], double *__restri
 }
 
 __device__ __forceinline__ void accumulate(double (&acc)[17], bool keep, double px, double py, double pz, double qx,
-                                           double qy, double qz, double dF, const StepArgs &A) {
+                                           double qy, double qz, double dF, const StepDyn &A) {
     const double ax = px - A.pivot_p[0], ay = py - A.pivot_p[1], az = pz - A.pivot_p[2];
     const double bx = qx - A.pivot_q[0], by = qy - A.pivot_q[1], bz = qz - A.pivot_q[2];
     const double w = keep ? 1.0 : 0.0;
@@ -97,6 +136,9 @@ __device__ __forceinline__ void accumulate(double (&acc)[17], bool keep, double 
 
 template <int KC>
 __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(StepArgs A) {
+    const StepDyn *__restrict__ dynp = A.dyn;
+    if (dynp->done) return;  // uniform over the grid
+    const StepDyn D = *dynp;
     const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t t = lb * 256u + threadIdx.x;
     const bool live = t < A.m;
@@ -116,7 +158,7 @@ __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(Step
             slot = orig;
         }
         const Pt4 s = A.src.pts[pos];
-        xform(A.M, s.x, s.y, s.z, px, py, pz);  // CurSrcPoint = R*s + T (:86)
+        xform(D.M, s.x, s.y, s.z, px, py, pz);  // CurSrcPoint = R*s + T (:86)
     }
     // ---- forward: K-th nearest target point of p (:89-92) ----
     const double fmax_d2 = A.exact ? PCR_INF : A.thr_fwd;
@@ -142,17 +184,17 @@ __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(Step
         qx = qpt.x;
         qy = qpt.y;
         qz = qpt.z;
-        const double ux = qx - A.M.t[0], uy = qy - A.M.t[1], uz = qz - A.M.t[2];
-        sx = A.rinv[0] * ux + A.rinv[3] * uy + A.rinv[6] * uz;
-        sy = A.rinv[1] * ux + A.rinv[4] * uy + A.rinv[7] * uz;
-        sz = A.rinv[2] * ux + A.rinv[5] * uy + A.rinv[8] * uz;
+        const double ux = qx - D.M.t[0], uy = qy - D.M.t[1], uz = qz - D.M.t[2];
+        sx = D.rinv[0] * ux + D.rinv[3] * uy + D.rinv[6] * uz;
+        sy = D.rinv[1] * ux + D.rinv[4] * uy + D.rinv[7] * uz;
+        sz = D.rinv[2] * ux + D.rinv[5] * uy + D.rinv[8] * uz;
     }
     TopK<1> rt;
     rt.d[0] = dF;
     rt.idx[0] = orig;
     const bool rev_active = need_rev && isfinite(sx) && isfinite(sy) && isfinite(sz);
     if (rev_active)
-        lane_search<1>(A.src, A.tsrc, qx, qy, qz, sx, sy, sz, PCR_INF, A.rev_bound_scale, A.rev_extra_margin, rt, my_rows);
+        lane_search<1>(A.src, A.tsrc, qx, qy, qz, sx, sy, sz, PCR_INF, D.rev_bound_scale, D.rev_extra_margin, rt, my_rows);
     uint32_t r = PCR_NO_INDEX;
     bool keep = false;
     if (need_rev) {
@@ -162,7 +204,7 @@ __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(Step
         keep = passF && dR < A.thr_rev;                           // strict < (:98)
     }
     if (live) {
-        accumulate(acc, keep, px, py, pz, qx, qy, qz, dF, A);
+        accumulate(acc, keep, px, py, pz, qx, qy, qz, dF, D);
         if (A.out_fwd) A.out_fwd[slot] = found ? j : PCR_NO_INDEX;
         if (A.out_rev) A.out_rev[slot] = r;
         if (A.out_keep) A.out_keep[slot] = keep ? 1 : 0;
@@ -173,6 +215,9 @@ __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(Step
 // Small clouds: both searches as tiled brute force (LDS-staged tiles, broadcast reads).
 template <int KC>
 __global__ void __launch_bounds__(256) icp_step_brute_kernel(StepArgs A) {
+    const StepDyn *__restrict__ dynp = A.dyn;
+    if (dynp->done) return;
+    const StepDyn D = *dynp;
     __shared__ Pt4 tile[512];
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const bool live = t < A.m;
@@ -192,7 +237,7 @@ __global__ void __launch_bounds__(256) icp_step_brute_kernel(StepArgs A) {
             slot = orig;
         }
         const Pt4 s = A.src.pts[pos];
-        xform(A.M, s.x, s.y, s.z, px, py, pz);
+        xform(D.M, s.x, s.y, s.z, px, py, pz);
     }
     const bool fin = live && isfinite(px) && isfinite(py) && isfinite(pz);
     TopK<KC> top;
@@ -235,7 +280,7 @@ __global__ void __launch_bounds__(256) icp_step_brute_kernel(StepArgs A) {
         keep = passF && dR < A.thr_rev;
     }
     if (live) {
-        accumulate(acc, keep, px, py, pz, qx, qy, qz, dF, A);
+        accumulate(acc, keep, px, py, pz, qx, qy, qz, dF, D);
         if (A.out_fwd) A.out_fwd[slot] = found ? j : PCR_NO_INDEX;
         if (A.out_rev) A.out_rev[slot] = r;
         if (A.out_keep) A.out_keep[slot] = keep ? 1 : 0;
@@ -264,7 +309,7 @@ __global__ void __launch_bounds__(256) fold_partials_kernel(const double *__rest
 // Pair lists that already exist (a host-side rejection stage produced them): the same 17 sums over P explicit
 // pairs, same block reduction and fold.  pairs are AoS double[3P].
 __global__ void __launch_bounds__(256) reduce_pairs_kernel(const double *__restrict__ pp, const double *__restrict__ pq,
-                                                           uint32_t P, StepArgs A) {
+                                                           uint32_t P, StepDyn D, double *block_partials) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     double acc[17];
 #pragma unroll
@@ -272,135 +317,156 @@ __global__ void __launch_bounds__(256) reduce_pairs_kernel(const double *__restr
     if (t < P) {
         const double px = pp[3 * (size_t)t], py = pp[3 * (size_t)t + 1], pz = pp[3 * (size_t)t + 2];
         const double qx = pq[3 * (size_t)t], qy = pq[3 * (size_t)t + 1], qz = pq[3 * (size_t)t + 2];
-        accumulate(acc, true, px, py, pz, qx, qy, qz, sqdist3(px, py, pz, qx, qy, qz), A);
+        accumulate(acc, true, px, py, pz, qx, qy, qz, sqdist3(px, py, pz, qx, qy, qz), D);
     }
-    block_reduce17(acc, A.block_partials, blockIdx.x, gridDim.x);
+    block_reduce17(acc, block_partials, blockIdx.x, gridDim.x);
 }
 
-static bool invert3(const double R[9], double inv[9], double &defect) {
-    // column-major: R(r,c) = R[c*3+r]
-    auto at = [&](int r, int c) { return R[c * 3 + r]; };
-    const double c00 = at(1, 1) * at(2, 2) - at(1, 2) * at(2, 1);
-    const double c01 = at(1, 2) * at(2, 0) - at(1, 0) * at(2, 2);
-    const double c02 = at(1, 0) * at(2, 1) - at(1, 1) * at(2, 0);
-    const double det = at(0, 0) * c00 + at(0, 1) * c01 + at(0, 2) * c02;
-    if (!(fabs(det) > 0.5)) return false;
-    const double id = 1.0 / det;
-    double m[3][3];
-    m[0][0] = c00 * id;
-    m[0][1] = (at(0, 2) * at(2, 1) - at(0, 1) * at(2, 2)) * id;
-    m[0][2] = (at(0, 1) * at(1, 2) - at(0, 2) * at(1, 1)) * id;
-    m[1][0] = c01 * id;
-    m[1][1] = (at(0, 0) * at(2, 2) - at(0, 2) * at(2, 0)) * id;
-    m[1][2] = (at(0, 2) * at(1, 0) - at(0, 0) * at(1, 2)) * id;
-    m[2][0] = c02 * id;
-    m[2][1] = (at(0, 1) * at(2, 0) - at(0, 0) * at(2, 1)) * id;
-    m[2][2] = (at(0, 0) * at(1, 1) - at(0, 1) * at(1, 0)) * id;
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) inv[c * 3 + r] = m[r][c];
-    defect = 0;
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            double s = 0;
-            for (int r = 0; r < 3; ++r) s += at(r, i) * at(r, j);
-            defect = fmax(defect, fabs(s - (i == j ? 1.0 : 0.0)));
+static double clouds_scale(const pcr_cloud *a, const pcr_cloud *b) {
+    double scale = 0;
+    for (int i = 0; i < 3; ++i) {
+        scale = fmax(scale, fmax(fabs(a->lo[i]), fabs(a->hi[i])));
+        scale = fmax(scale, fmax(fabs(b->lo[i]), fabs(b->hi[i])));
+    }
+    return scale;
+}
+
+static void cloud_centre(const pcr_cloud *c, double out[3]) {
+    for (int a = 0; a < 3; ++a) out[a] = 0.5 * (c->lo[a] + c->hi[a]);
+}
+
+// ---- device-resident fit loop: state, solve and convergence on the device ---------------------------------------
+struct FitDev {
+    StepDyn dyn;  // first member: the step kernels read it through a StepDyn pointer
+    double c_src[3], c_tgt[3], cloud_scale;
+    double uniq;  // CUniqueData of the target: scales the MSE thresholds
+    pcr_convergence_params conv;
+    int32_t conv_enabled;
+    // CDefaultConvergenceCriteria state (DefaultConvergenceCriterial.h:43-48)
+    double pre_mse, cur_mse, pre_rot[9];
+    uint32_t similar;
+    uint32_t iteration;  // completed iterations
+    int32_t state;       // pcr_fit_state
+    uint32_t traj_cap;
+    double last_n;
+};
+
+__global__ void fit_init_kernel(FitDev value, FitDev *dst) { *dst = value; }
+
+// One thread: what CIterativeFit::_fitStepV does after the correspondences (IterativeFit.cpp:156-174) --
+// computeRotationAndTranslation, then the convergence criteria -- followed by the preparation of the next step.
+__global__ void fit_solve_kernel(FitDev *F, const double *__restrict__ partials, double *__restrict__ traj) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (F->dyn.done) return;
+    double part[17];
+    for (int i = 0; i < 17; ++i) part[i] = partials[i];
+    const uint32_t it = F->iteration + 1;  // the reference counts from 1 (IterativeFit.cpp:121-123)
+    F->iteration = it;
+    F->last_n = part[0];
+    double R[9], T[3];
+    for (int i = 0; i < 9; ++i) R[i] = F->dyn.M.r[i];
+    for (int i = 0; i < 3; ++i) T[i] = F->dyn.M.t[i];
+    double *row = (traj && it <= F->traj_cap) ? traj + (size_t)(it - 1) * 14 : nullptr;
+    if (!(part[0] >= 1.0)) {  // the reference divides by zero here (RegUtilityFunctions.cpp:71)
+        F->state = PCR_FIT_NO_CORRESPONDENCES;
+        F->dyn.done = 1;
+        if (row) {
+            for (int i = 0; i < 9; ++i) row[i] = R[i];
+            for (int i = 0; i < 3; ++i) row[9 + i] = T[i];
+            row[12] = __builtin_nan("");
+            row[13] = 0.0;
         }
-    return true;
-}
-
-static void cloud_scale(const pcr_cloud *c, double &scale) {
-    for (int a = 0; a < 3; ++a) scale = fmax(scale, fmax(fabs(c->lo[a]), fabs(c->hi[a])));
+        return;
+    }
+    double mse;
+    solve_rigid_core(part, F->dyn.pivot_p, F->dyn.pivot_q, R, T, nullptr, nullptr, &mse);
+    if (row) {
+        for (int i = 0; i < 9; ++i) row[i] = R[i];
+        for (int i = 0; i < 3; ++i) row[9 + i] = T[i];
+        row[12] = mse;
+        row[13] = part[0];
+    }
+    // ---- CDefaultConvergenceCriteria::_isConvergedV (DefaultConvergenceCriterial.cpp:69-83): short-circuit OR
+    int state = PCR_FIT_NOT_CONVERGED;
+    bool converged = false;
+    if (F->conv_enabled) {
+        const pcr_convergence_params &c = F->conv;
+        uint32_t similar = F->similar;
+        auto gate = [&](int st) {  // the MIST counter shared by the three tests (:111-123)
+            if (similar < c.max_similar) {
+                ++similar;
+                return false;
+            }
+            similar = 0;
+            state = st;
+            return true;
+        };
+        do {
+            if (it >= c.max_iterations) {  // (:86-99)
+                state = PCR_FIT_ITERATIONS;
+                if (!c.failure_after_max_iterations) {
+                    converged = true;
+                    break;
+                }
+            }
+            double rot = 0;  // (:103-133); T is the ACCUMULATED translation
+            for (int i = 0; i < 9; ++i) rot += (F->pre_rot[i] - R[i]) * (F->pre_rot[i] - R[i]);
+            const double tr = T[0] * T[0] + T[1] * T[1] + T[2] * T[2];
+            if (rot < c.rotation_threshold && tr < c.translation_threshold && gate(PCR_FIT_TRANSFORM)) {
+                converged = true;
+                break;
+            }
+            F->cur_mse = mse;  // (:137-170)
+            if (fabs(F->cur_mse - F->pre_mse) < c.abs_mse * F->uniq && gate(PCR_FIT_ABS_MSE)) {
+                converged = true;
+                break;
+            }
+            if (fabs(F->cur_mse - F->pre_mse) / F->pre_mse < c.rel_mse * F->uniq && gate(PCR_FIT_REL_MSE)) {  // (:174-207)
+                converged = true;
+                break;
+            }
+        } while (false);
+        F->similar = similar;
+        F->pre_mse = F->cur_mse;  // (:77-79)
+        for (int i = 0; i < 9; ++i) F->pre_rot[i] = R[i];
+    } else {
+        F->cur_mse = mse;
+    }
+    F->state = state;
+    // ---- next iteration's constants
+    StepDyn next;
+    const bool ok = make_dyn(R, T, F->c_src, F->c_tgt, F->cloud_scale, next, nullptr);
+    if (!ok) {
+        F->state = PCR_FIT_DEGENERATE;
+        converged = true;
+    }
+    next.done = converged ? 1u : 0u;
+    F->dyn = next;
 }
 
 }  // namespace pcr
 
 using namespace pcr;
 
-extern "C" {
+struct pcr_fit {
+    pcr_ctx *ctx;
+    const pcr_index *src, *tgt;
+    StepArgs args;
+    uint32_t nb, kc, traj_cap;
+    FitDev *dev_d;        // device state
+    FitDev *dev_h;        // pinned host mirror (pcr_fit_read)
+    double *partials_d;   // [17]
+    double *block_partials_d;
+    double *traj_d;       // [traj_cap][14]
+    FitDev init;          // host-side template of the state (reset copies it)
+};
 
-int pcr_icp_pivots(const pcr_index *src, const pcr_index *tgt, const double R[9], const double T[3],
-                   double pivot_p[3], double pivot_q[3]) {
-    PCR_REQUIRE(src && tgt && R && T && pivot_p && pivot_q, "pcr_icp_pivots: NULL argument");
-    double c[3];
-    for (int a = 0; a < 3; ++a) {
-        c[a] = 0.5 * (src->cloud->lo[a] + src->cloud->hi[a]);
-        pivot_q[a] = 0.5 * (tgt->cloud->lo[a] + tgt->cloud->hi[a]);
-    }
-    for (int r = 0; r < 3; ++r) pivot_p[r] = R[r] * c[0] + R[3 + r] * c[1] + R[6 + r] * c[2] + T[r];
-    return PCR_OK;
-}
-
-int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const uint32_t *sample_idx_d,
-                   uint32_t sample_begin, uint32_t m, const double R[9], const double T[3], uint32_t k,
-                   double thr_fwd_sq, double thr_rev_sq, uint32_t flags, double *partials_d, uint32_t *out_fwd_d,
-                   uint32_t *out_rev_d, uint8_t *out_keep_d) {
-    PCR_REQUIRE(ctx && src && tgt && R && T && partials_d, "pcr_icp_step_d: NULL argument");
-    PCR_REQUIRE(src->ctx == ctx && tgt->ctx == ctx, "pcr_icp_step_d: index belongs to another context");
-    PCR_REQUIRE(src->kind == tgt->kind, "pcr_icp_step_d: source and target index must be of the same kind");
-    PCR_REQUIRE(k >= 1 && k <= tgt->n, "pcr_icp_step_d: k=%u out of range for %u target points", k, tgt->n);
-    if (k > PCR_MAX_K) {
-        set_last_error("pcr_icp_step_d: k=%u above PCR_MAX_K=%u", k, PCR_MAX_K);
-        return PCR_E_UNSUPPORTED;
-    }
-    if (!sample_idx_d)
-        PCR_REQUIRE((uint64_t)sample_begin + m <= src->n, "pcr_icp_step_d: sample range [%u,%u+%u) exceeds %u source points",
-                    sample_begin, sample_begin, m, src->n);
-    for (int i = 0; i < 9; ++i) PCR_REQUIRE(isfinite(R[i]), "pcr_icp_step_d: R is not finite");
-    for (int i = 0; i < 3; ++i) PCR_REQUIRE(isfinite(T[i]), "pcr_icp_step_d: T is not finite");
-    PCR_HIP(hipSetDevice(ctx->device));
-
-    StepArgs A;
-    memset(&A, 0, sizeof A);
-    double defect = 0;
-    PCR_REQUIRE(invert3(R, A.rinv, defect) && defect <= 1e-3,
-                "pcr_icp_step_d: R must be a rotation to within 1e-3 (orthogonality defect %g)", defect);
-    A.src = src->view;
-    A.tgt = tgt->view;
-    A.tsrc = src->tpts_d;
-    A.src_pos_of = src->pos_of_d;
-    A.src_order = src->order_d;
-    A.sample_idx = sample_idx_d;
-    A.sample_begin = sample_idx_d ? 0 : sample_begin;
-    A.m = m;
-    memcpy(A.M.r, R, sizeof A.M.r);
-    memcpy(A.M.t, T, sizeof A.M.t);
-    A.k = (int)k;
-    A.thr_fwd = thr_fwd_sq;
-    A.thr_rev = thr_rev_sq;
-    A.exact = (flags & PCR_STEP_EXACT_INDICES) ? 1u : 0u;
-    // |R v| >= sigma_min |v| with sigma_min^2 >= 1 - 3*defect (Gershgorin on R^T R)
-    A.rev_bound_scale = (1.0 - 3.0 * defect) * (1.0 - 1.8189894035458565e-12);
-    double scale = fabs(T[0]) + fabs(T[1]) + fabs(T[2]);
-    cloud_scale(src->cloud, scale);
-    cloud_scale(tgt->cloud, scale);
-    A.rev_extra_margin = 3.637978807091713e-12 * scale;  // 2^-38
-    pcr_icp_pivots(src, tgt, R, T, A.pivot_p, A.pivot_q);
-    A.out_fwd = out_fwd_d;
-    A.out_rev = out_rev_d;
-    A.out_keep = out_keep_d;
-
-    const uint32_t nb = m ? (m + 255) / 256 : 0;
-    if (nb == 0) {
-        PCR_HIP(hipMemsetAsync(partials_d, 0, sizeof(double) * 17, ctx->stream));
-        return PCR_OK;
-    }
-    if ((size_t)nb * 17 > ctx->block_partials_cap) {
-        if (ctx->block_partials_d) {
-            PCR_HIP(hipStreamSynchronize(ctx->stream));
-            hipFree(ctx->block_partials_d);
-            ctx->block_partials_d = nullptr;
-            ctx->block_partials_cap = 0;
-        }
-        PCR_HIP(hipMalloc(&ctx->block_partials_d, sizeof(double) * 17 * (size_t)nb));
-        ctx->block_partials_cap = (size_t)nb * 17;
-    }
-    A.block_partials = ctx->block_partials_d;
-
-    // CPointCloud::transform of the whole source (:73-74), in index order
-    {
+static void launch_step_kernels(pcr_ctx *ctx, const pcr_index *src, const StepArgs &A, uint32_t nb, uint32_t k,
+                                double *partials_d) {
+    {  // CPointCloud::transform of the whole source (:73-74), in index order
         ProfScope ps(ctx, PCR_PROF_TRANSFORM);
         hipLaunchKernelGGL(transform_kernel, dim3(min(2048u, (src->n + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const Pt4 *)src->pts_d, src->n, A.M, src->tpts_d);
+                           (const Pt4 *)src->pts_d, src->n, A.dyn, src->tpts_d);
     }
 #define LAUNCH_STEP(KC)                                                                                \
     do {                                                                                               \
@@ -425,9 +491,100 @@ int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
 #undef LAUNCH_STEP
     {
         ProfScope ps(ctx, PCR_PROF_FOLD);
-        hipLaunchKernelGGL(fold_partials_kernel, dim3(17), dim3(256), 0, ctx->stream,
-                           (const double *)ctx->block_partials_d, nb, partials_d);
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(17), dim3(256), 0, ctx->stream, (const double *)A.block_partials, nb,
+                           partials_d);
     }
+}
+
+// argument checks and the iteration-independent part of StepArgs, shared by the single step and the fit loop
+static int prepare_step_args(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const uint32_t *sample_idx_d,
+                             uint32_t sample_begin, uint32_t m, uint32_t k, double thr_fwd_sq, double thr_rev_sq,
+                             uint32_t flags, StepArgs &A, const char *who) {
+    PCR_REQUIRE(src->ctx == ctx && tgt->ctx == ctx, "%s: index belongs to another context", who);
+    PCR_REQUIRE(src->kind == tgt->kind, "%s: source and target index must be of the same kind", who);
+    PCR_REQUIRE(k >= 1 && k <= tgt->n, "%s: k=%u out of range for %u target points", who, k, tgt->n);
+    if (k > PCR_MAX_K) {
+        set_last_error("%s: k=%u above PCR_MAX_K=%u", who, k, PCR_MAX_K);
+        return PCR_E_UNSUPPORTED;
+    }
+    if (!sample_idx_d)
+        PCR_REQUIRE((uint64_t)sample_begin + m <= src->n, "%s: sample range [%u,%u+%u) exceeds %u source points", who,
+                    sample_begin, sample_begin, m, src->n);
+    memset(&A, 0, sizeof A);
+    A.src = src->view;
+    A.tgt = tgt->view;
+    A.tsrc = src->tpts_d;
+    A.src_pos_of = src->pos_of_d;
+    A.src_order = src->order_d;
+    A.sample_idx = sample_idx_d;
+    A.sample_begin = sample_idx_d ? 0 : sample_begin;
+    A.m = m;
+    A.k = (int)k;
+    A.thr_fwd = thr_fwd_sq;
+    A.thr_rev = thr_rev_sq;
+    A.exact = (flags & PCR_STEP_EXACT_INDICES) ? 1u : 0u;
+    return PCR_OK;
+}
+
+extern "C" {
+
+int pcr_icp_pivots(const pcr_index *src, const pcr_index *tgt, const double R[9], const double T[3],
+                   double pivot_p[3], double pivot_q[3]) {
+    PCR_REQUIRE(src && tgt && R && T && pivot_p && pivot_q, "pcr_icp_pivots: NULL argument");
+    double c_src[3], c_tgt[3];
+    cloud_centre(src->cloud, c_src);
+    cloud_centre(tgt->cloud, c_tgt);
+    for (int r = 0; r < 3; ++r) {
+        pivot_p[r] = R[r] * c_src[0] + R[3 + r] * c_src[1] + R[6 + r] * c_src[2] + T[r];
+        pivot_q[r] = c_tgt[r];
+    }
+    return PCR_OK;
+}
+
+int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const uint32_t *sample_idx_d,
+                   uint32_t sample_begin, uint32_t m, const double R[9], const double T[3], uint32_t k,
+                   double thr_fwd_sq, double thr_rev_sq, uint32_t flags, double *partials_d, uint32_t *out_fwd_d,
+                   uint32_t *out_rev_d, uint8_t *out_keep_d) {
+    PCR_REQUIRE(ctx && src && tgt && R && T && partials_d, "pcr_icp_step_d: NULL argument");
+    StepArgs A;
+    int rc = prepare_step_args(ctx, src, tgt, sample_idx_d, sample_begin, m, k, thr_fwd_sq, thr_rev_sq, flags, A,
+                               "pcr_icp_step_d");
+    if (rc != PCR_OK) return rc;
+    for (int i = 0; i < 9; ++i) PCR_REQUIRE(isfinite(R[i]), "pcr_icp_step_d: R is not finite");
+    for (int i = 0; i < 3; ++i) PCR_REQUIRE(isfinite(T[i]), "pcr_icp_step_d: T is not finite");
+    PCR_HIP(hipSetDevice(ctx->device));
+    StepDyn D;
+    double c_src[3], c_tgt[3], defect = 0;
+    cloud_centre(src->cloud, c_src);
+    cloud_centre(tgt->cloud, c_tgt);
+    PCR_REQUIRE(make_dyn(R, T, c_src, c_tgt, clouds_scale(src->cloud, tgt->cloud), D, &defect),
+                "pcr_icp_step_d: R must be a rotation to within 1e-3 (orthogonality defect %g)", defect);
+    A.out_fwd = out_fwd_d;
+    A.out_rev = out_rev_d;
+    A.out_keep = out_keep_d;
+
+    const uint32_t nb = m ? (m + 255) / 256 : 0;
+    if (nb == 0) {
+        PCR_HIP(hipMemsetAsync(partials_d, 0, sizeof(double) * 17, ctx->stream));
+        return PCR_OK;
+    }
+    if ((size_t)nb * 17 > ctx->block_partials_cap) {
+        if (ctx->block_partials_d) {
+            PCR_HIP(hipStreamSynchronize(ctx->stream));
+            hipFree(ctx->block_partials_d);
+            ctx->block_partials_d = nullptr;
+            ctx->block_partials_cap = 0;
+        }
+        PCR_HIP(hipMalloc(&ctx->block_partials_d, sizeof(double) * 17 * (size_t)nb));
+        ctx->block_partials_cap = (size_t)nb * 17;
+    }
+    A.block_partials = ctx->block_partials_d;
+    StepDyn *dyn_d = (StepDyn *)ctx_scratch(ctx, 5, sizeof(StepDyn));
+    if (!dyn_d) return PCR_E_NOMEM;
+    A.dyn = dyn_d;
+    // the per-iteration values travel as a kernel argument of a one-thread kernel: stream-ordered, no staging buffer
+    hipLaunchKernelGGL(set_dyn_kernel, dim3(1), dim3(1), 0, ctx->stream, D, dyn_d);
+    launch_step_kernels(ctx, src, A, nb, k, partials_d);
     PCR_HIP(hipGetLastError());
     return PCR_OK;
 }
@@ -492,18 +649,18 @@ int pcr_reduce_pairs(pcr_ctx *ctx, const double *pair_p, const double *pair_q, u
         set_last_error("pcr_reduce_pairs: device allocation for %u pairs failed", P);
         return PCR_E_NOMEM;
     }
-    StepArgs A;
-    memset(&A, 0, sizeof A);
-    memcpy(A.pivot_p, pivot_p, sizeof A.pivot_p);
-    memcpy(A.pivot_q, pivot_q, sizeof A.pivot_q);
-    A.block_partials = buf + 2 * n3;
-    double *res_d = A.block_partials + 17 * (size_t)nb;
+    StepDyn D;
+    memset(&D, 0, sizeof D);
+    memcpy(D.pivot_p, pivot_p, sizeof D.pivot_p);
+    memcpy(D.pivot_q, pivot_q, sizeof D.pivot_q);
+    double *block_partials = buf + 2 * n3;
+    double *res_d = block_partials + 17 * (size_t)nb;
     hipError_t e = hipMemcpyAsync(buf, pair_p, sizeof(double) * n3, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(buf + n3, pair_q, sizeof(double) * n3, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(reduce_pairs_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const double *)buf,
-                           (const double *)(buf + n3), P, A);
-        hipLaunchKernelGGL(fold_partials_kernel, dim3(17), dim3(256), 0, ctx->stream, (const double *)A.block_partials, nb,
+                           (const double *)(buf + n3), P, D, block_partials);
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(17), dim3(256), 0, ctx->stream, (const double *)block_partials, nb,
                            res_d);
         e = hipGetLastError();
     }
@@ -511,6 +668,138 @@ int pcr_reduce_pairs(pcr_ctx *ctx, const double *pair_p, const double *pair_q, u
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     hipFree(buf);
     PCR_HIP(e);
+    return PCR_OK;
+}
+
+// ---- the device-resident loop (CIterativeFit::__fitLoop, IterativeFit.cpp:119-175) ------------------------------
+
+int pcr_fit_destroy(pcr_fit *f) {
+    if (!f) return PCR_OK;
+    hipSetDevice(f->ctx->device);
+    hipStreamSynchronize(f->ctx->stream);
+    if (f->dev_d) hipFree(f->dev_d);
+    if (f->dev_h) hipHostFree(f->dev_h);
+    if (f->partials_d) hipFree(f->partials_d);
+    if (f->block_partials_d) hipFree(f->block_partials_d);
+    if (f->traj_d) hipFree(f->traj_d);
+    delete f;
+    return PCR_OK;
+}
+
+int pcr_fit_create(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const uint32_t *sample_idx_d,
+                   uint32_t sample_begin, uint32_t m, uint32_t k, double thr_fwd_sq, double thr_rev_sq,
+                   const pcr_convergence_params *conv, double unique_sq_dist, uint32_t traj_cap, pcr_fit **out) {
+    PCR_REQUIRE(ctx && src && tgt && out, "pcr_fit_create: NULL argument");
+    *out = nullptr;
+    PCR_HIP(hipSetDevice(ctx->device));
+    pcr_fit *f = new pcr_fit();
+    f->ctx = ctx;
+    f->src = src;
+    f->tgt = tgt;
+    int rc = prepare_step_args(ctx, src, tgt, sample_idx_d, sample_begin, m, k, thr_fwd_sq, thr_rev_sq, 0u, f->args,
+                               "pcr_fit_create");
+    if (rc != PCR_OK) {
+        delete f;
+        return rc;
+    }
+    f->nb = m ? (m + 255) / 256 : 0;
+    f->kc = k;
+    f->traj_cap = traj_cap;
+    FitDev &I = f->init;
+    memset(&I, 0, sizeof I);
+    cloud_centre(src->cloud, I.c_src);
+    cloud_centre(tgt->cloud, I.c_tgt);
+    I.cloud_scale = clouds_scale(src->cloud, tgt->cloud);
+    I.uniq = unique_sq_dist;
+    if (conv) {
+        I.conv = *conv;
+        I.conv_enabled = 1;
+    }
+    I.traj_cap = traj_cap;
+    hipError_t e = hipMalloc(&f->dev_d, sizeof(FitDev));
+    if (e == hipSuccess) e = hipHostMalloc(&f->dev_h, sizeof(FitDev));
+    if (e == hipSuccess) e = hipMalloc(&f->partials_d, sizeof(double) * 32);
+    if (e == hipSuccess) e = hipMalloc(&f->block_partials_d, sizeof(double) * 17 * (size_t)(f->nb ? f->nb : 1));
+    if (e == hipSuccess && traj_cap) e = hipMalloc(&f->traj_d, sizeof(double) * 14 * (size_t)traj_cap);
+    if (e != hipSuccess) {
+        set_last_error("pcr_fit_create: allocation failed: %s", hipGetErrorString(e));
+        pcr_fit_destroy(f);
+        return e == hipErrorOutOfMemory ? PCR_E_NOMEM : PCR_E_HIP;
+    }
+    f->args.dyn = &f->dev_d->dyn;
+    f->args.block_partials = f->block_partials_d;
+    const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, zero[3] = {0, 0, 0};
+    rc = pcr_fit_reset(f, eye, zero);
+    if (rc != PCR_OK) {
+        pcr_fit_destroy(f);
+        return rc;
+    }
+    *out = f;
+    return PCR_OK;
+}
+
+int pcr_fit_reset(pcr_fit *f, const double R[9], const double T[3]) {
+    PCR_REQUIRE(f && R && T, "pcr_fit_reset: NULL argument");
+    for (int i = 0; i < 9; ++i) PCR_REQUIRE(isfinite(R[i]), "pcr_fit_reset: R is not finite");
+    for (int i = 0; i < 3; ++i) PCR_REQUIRE(isfinite(T[i]), "pcr_fit_reset: T is not finite");
+    PCR_HIP(hipSetDevice(f->ctx->device));
+    FitDev I = f->init;
+    double defect = 0;
+    PCR_REQUIRE(make_dyn(R, T, I.c_src, I.c_tgt, I.cloud_scale, I.dyn, &defect),
+                "pcr_fit_reset: R must be a rotation to within 1e-3 (orthogonality defect %g)", defect);
+    // CDefaultConvergenceCriteria::__init (DefaultConvergenceCriterial.cpp:21-25); m_PreRot is uninitialised in the
+    // reference: NaN makes the first transformation test false, as garbage far from a rotation does
+    I.pre_mse = I.cur_mse = 1.7976931348623157e308;
+    for (int i = 0; i < 9; ++i) I.pre_rot[i] = __builtin_nan("");
+    I.similar = 0;
+    I.iteration = 0;
+    I.state = PCR_FIT_NOT_CONVERGED;
+    hipLaunchKernelGGL(fit_init_kernel, dim3(1), dim3(1), 0, f->ctx->stream, I, f->dev_d);
+    PCR_HIP(hipGetLastError());
+    return PCR_OK;
+}
+
+int pcr_fit_enqueue_step(pcr_fit *f) {
+    PCR_REQUIRE(f, "pcr_fit_enqueue_step: NULL argument");
+    PCR_HIP(hipSetDevice(f->ctx->device));
+    if (f->nb == 0) {
+        PCR_HIP(hipMemsetAsync(f->partials_d, 0, sizeof(double) * 17, f->ctx->stream));
+        return PCR_OK;
+    }
+    launch_step_kernels(f->ctx, f->src, f->args, f->nb, f->kc, f->partials_d);
+    PCR_HIP(hipGetLastError());
+    return PCR_OK;
+}
+
+double *pcr_fit_partials_d(pcr_fit *f) { return f ? f->partials_d : nullptr; }
+
+int pcr_fit_enqueue_solve(pcr_fit *f) {
+    PCR_REQUIRE(f, "pcr_fit_enqueue_solve: NULL argument");
+    PCR_HIP(hipSetDevice(f->ctx->device));
+    hipLaunchKernelGGL(fit_solve_kernel, dim3(1), dim3(64), 0, f->ctx->stream, f->dev_d, (const double *)f->partials_d,
+                       f->traj_d);
+    PCR_HIP(hipGetLastError());
+    return PCR_OK;
+}
+
+int pcr_fit_read(pcr_fit *f, double R[9], double T[3], uint32_t *iterations, int *state, double *mse, double *pairs,
+                 double *traj, uint32_t traj_rows) {
+    PCR_REQUIRE(f, "pcr_fit_read: NULL argument");
+    PCR_HIP(hipSetDevice(f->ctx->device));
+    PCR_HIP(hipMemcpyAsync(f->dev_h, f->dev_d, sizeof(FitDev), hipMemcpyDeviceToHost, f->ctx->stream));
+    PCR_HIP(hipStreamSynchronize(f->ctx->stream));
+    const FitDev &H = *f->dev_h;
+    if (R) memcpy(R, H.dyn.M.r, sizeof(double) * 9);
+    if (T) memcpy(T, H.dyn.M.t, sizeof(double) * 3);
+    if (iterations) *iterations = H.iteration;
+    if (state) *state = H.state;
+    if (mse) *mse = H.cur_mse;
+    if (pairs) *pairs = H.last_n;
+    if (traj && traj_rows && f->traj_d) {
+        uint32_t rows = H.iteration < f->traj_cap ? H.iteration : f->traj_cap;
+        if (rows > traj_rows) rows = traj_rows;
+        if (rows) PCR_HIP(hipMemcpy(traj, f->traj_d, sizeof(double) * 14 * rows, hipMemcpyDeviceToHost));
+    }
     return PCR_OK;
 }
 

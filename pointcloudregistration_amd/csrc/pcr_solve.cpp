@@ -1,123 +1,6 @@
-// libpcr.so -- host part of one ICRP iteration: the 3x3 problem the 17 partial sums reduce to.
-//
-// Replaces CTransformationEstimationSVD2::__computeRelativeRotationAndTranslation
-// (TransformationEstimationSVD2.cpp:98-117) and CBaseTransformationEstimation::
-// accumulateTransformation (BaseTransformationEstimation.h:28-32).  The reference forms
-// H = sum (a_i - abar)(b_i - bbar)^T from explicit de-meaned copies; here
-// H = sum a' b'^T - n abar' bbar'^T with a' = a - pivot_p, b' = b - pivot_q (pivots near the
-// centroids, so the subtraction does not cancel), which is the same matrix.
-// The SVD is a one-sided (Hestenes) Jacobi iteration -- Eigen is not a dependency.  For
-// non-degenerate H the result R = V diag(1,1,+-1) U^T is the unique polar factor, so it does not
-// depend on which SVD algorithm produced U and V.
-#include <math.h>
+// libpcr.so -- host entry point of the 3x3 solve (the math lives in solve_core.h, shared with the device loop).
 #include <string.h>
-#include "pcr_internal.h"
-
-namespace {
-
-// all matrices column-major: A(r,c) = A[c*3+r]
-inline double &el(double *A, int r, int c) { return A[c * 3 + r]; }
-inline double el(const double *A, int r, int c) { return A[c * 3 + r]; }
-
-double det3(const double *A) {
-    return el(A, 0, 0) * (el(A, 1, 1) * el(A, 2, 2) - el(A, 1, 2) * el(A, 2, 1)) -
-           el(A, 0, 1) * (el(A, 1, 0) * el(A, 2, 2) - el(A, 1, 2) * el(A, 2, 0)) +
-           el(A, 0, 2) * (el(A, 1, 0) * el(A, 2, 1) - el(A, 1, 1) * el(A, 2, 0));
-}
-
-void cross(const double *a, const double *b, double *o) {
-    o[0] = a[1] * b[2] - a[2] * b[1];
-    o[1] = a[2] * b[0] - a[0] * b[2];
-    o[2] = a[0] * b[1] - a[1] * b[0];
-}
-
-double norm3(const double *a) { return sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
-
-// H = U diag(S) V^T, S descending, U and V orthogonal.
-void svd3_hestenes(const double *H, double *U, double *S, double *V) {
-    double A[9];
-    double scale = 0;
-    for (int i = 0; i < 9; ++i) scale = fmax(scale, fabs(H[i]));
-    const double inv = scale > 0 ? 1.0 / scale : 1.0;
-    for (int i = 0; i < 9; ++i) A[i] = H[i] * inv;
-    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    memcpy(V, I3, sizeof I3);
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        bool rotated = false;
-        for (int i = 0; i < 2; ++i)
-            for (int j = i + 1; j < 3; ++j) {
-                double alpha = 0, beta = 0, gamma = 0;
-                for (int r = 0; r < 3; ++r) {
-                    alpha += el(A, r, i) * el(A, r, i);
-                    beta += el(A, r, j) * el(A, r, j);
-                    gamma += el(A, r, i) * el(A, r, j);
-                }
-                if (fabs(gamma) <= 1e-17 * sqrt(alpha * beta) || gamma == 0.0) continue;
-                rotated = true;
-                const double zeta = (beta - alpha) / (2.0 * gamma);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-                for (int r = 0; r < 3; ++r) {
-                    const double ai = el(A, r, i), aj = el(A, r, j);
-                    el(A, r, i) = c * ai - s * aj;
-                    el(A, r, j) = s * ai + c * aj;
-                    const double vi = el(V, r, i), vj = el(V, r, j);
-                    el(V, r, i) = c * vi - s * vj;
-                    el(V, r, j) = s * vi + c * vj;
-                }
-            }
-        if (!rotated) break;
-    }
-    // columns of A are now orthogonal: sigma_i = |col_i|
-    int order[3] = {0, 1, 2};
-    double sig[3];
-    for (int i = 0; i < 3; ++i) sig[i] = norm3(&A[i * 3]);
-    for (int i = 0; i < 3; ++i)
-        for (int j = i + 1; j < 3; ++j)
-            if (sig[order[j]] > sig[order[i]]) {
-                int t = order[i];
-                order[i] = order[j];
-                order[j] = t;
-            }
-    double Vs[9];
-    int rank = 0;
-    for (int i = 0; i < 3; ++i) {
-        const int o = order[i];
-        S[i] = sig[o] * scale;
-        for (int r = 0; r < 3; ++r) el(Vs, r, i) = el(V, r, o);
-        if (sig[o] > 1e-300 && sig[o] > 1e-15 * sig[order[0]]) {
-            for (int r = 0; r < 3; ++r) el(U, r, i) = el(A, r, o) / sig[o];
-            rank = i + 1;
-        }
-    }
-    memcpy(V, Vs, sizeof Vs);
-    // complete U to an orthonormal basis when H is rank deficient (planar / collinear pair sets)
-    if (rank == 0) {
-        memcpy(U, I3, sizeof I3);
-    } else if (rank == 1) {
-        double e[3] = {0, 0, 0};
-        int m = 0;  // axis least aligned with u0
-        for (int r = 1; r < 3; ++r)
-            if (fabs(el(U, r, 0)) < fabs(el(U, m, 0))) m = r;
-        e[m] = 1.0;
-        double u1[3], u2[3];
-        cross(&U[0], e, u1);
-        const double n1 = norm3(u1);
-        for (int r = 0; r < 3; ++r) u1[r] /= n1;
-        cross(&U[0], u1, u2);
-        for (int r = 0; r < 3; ++r) {
-            el(U, r, 1) = u1[r];
-            el(U, r, 2) = u2[r];
-        }
-    } else if (rank == 2) {
-        double u2[3];
-        cross(&U[0], &U[3], u2);
-        const double n2 = norm3(u2);
-        for (int r = 0; r < 3; ++r) el(U, r, 2) = u2[r] / n2;
-    }
-}
-
-}  // namespace
+#include "solve_core.h"
 
 extern "C" int pcr_solve_rigid(const double partials[17], const double pivot_p[3], const double pivot_q[3],
                                double R[9], double T[3], double Rc[9], double Tc[3], double *mse) {
@@ -127,36 +10,6 @@ extern "C" int pcr_solve_rigid(const double partials[17], const double pivot_p[3
         pcr::set_last_error("pcr_solve_rigid: no correspondence survived (n=%g)", n);
         return PCR_E_EMPTY;
     }
-    const double *Sa = partials + 1, *Sb = partials + 4, *Sab = partials + 7;
-    double ma[3], mb[3], ca[3], cb[3];
-    for (int a = 0; a < 3; ++a) {
-        ma[a] = Sa[a] / n;  // centroid offsets from the pivots
-        mb[a] = Sb[a] / n;
-        ca[a] = pivot_p[a] + ma[a];  // compute3DCentroid results (RegUtilityFunctions.cpp:44-72)
-        cb[a] = pivot_q[a] + mb[a];
-    }
-    double H[9];
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) el(H, r, c) = Sab[r * 3 + c] - n * ma[r] * mb[c];  // (:103)
-    double U[9], S[3], V[9];
-    svd3_hestenes(H, U, S, V);  // (:104-106)
-    if (det3(U) * det3(V) < 0)  // (:108-113)
-        for (int r = 0; r < 3; ++r) el(V, r, 2) = -el(V, r, 2);
-    double cr[9], ct[3];
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c)  // Rc = V * U^T (:115)
-            el(cr, r, c) = el(V, r, 0) * el(U, c, 0) + el(V, r, 1) * el(U, c, 1) + el(V, r, 2) * el(U, c, 2);
-    for (int r = 0; r < 3; ++r)  // Tc = bbar - Rc * abar (:116)
-        ct[r] = cb[r] - (el(cr, r, 0) * ca[0] + el(cr, r, 1) * ca[1] + el(cr, r, 2) * ca[2]);
-    double nr[9], nt[3];  // accumulateTransformation: R <- Rc*R ; T <- Rc*T + Tc
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c)
-            el(nr, r, c) = el(cr, r, 0) * el(R, 0, c) + el(cr, r, 1) * el(R, 1, c) + el(cr, r, 2) * el(R, 2, c);
-    for (int r = 0; r < 3; ++r) nt[r] = (el(cr, r, 0) * T[0] + el(cr, r, 1) * T[1] + el(cr, r, 2) * T[2]) + ct[r];
-    memcpy(R, nr, sizeof nr);
-    memcpy(T, nt, sizeof nt);
-    if (Rc) memcpy(Rc, cr, sizeof cr);
-    if (Tc) memcpy(Tc, ct, sizeof ct);
-    if (mse) *mse = partials[16] / n;
+    pcr::solve_rigid_core(partials, pivot_p, pivot_q, R, T, Rc, Tc, mse);
     return PCR_OK;
 }

@@ -1,0 +1,101 @@
+"""GPU parity of the device-resident fit loop (pcr_fit_*): solve, composition and convergence criteria run on the
+device, nothing leaves it between iterations.  Checked against the golden trajectories (reference tree + oracle
+loop) and, bit for bit, against the host path (pcr_icp_step_d + pcr_solve_rigid), which shares its source."""
+import numpy as np
+import pytest
+
+from conftest import case_inputs, golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(pcr, ctx, name):
+    g = golden(name + ".npz")
+    src, tgt = case_inputs(name, g)
+    six, tix = pcr.Index(ctx, pcr.Cloud(ctx, src)), pcr.Index(ctx, pcr.Cloud(ctx, tgt))
+    return g, src, tgt, six, tix
+
+
+@pytest.mark.parametrize("name", ["patch_k1", "patch_k4", "cube4096_k1", "cube4096_k4", "spheres40k_k4"])
+def test_device_loop_matches_golden(pcr, ctx, name):
+    g, src, tgt, six, tix = _setup(pcr, ctx, name)
+    k, U = int(g["k"]), float(g["uniq_tgt"])
+    fit = pcr.Fit(ctx, six, tix, k, U * g["sdft"], U * g["ndft"], conv=pcr.ConvergenceParams.regcfg(30),
+                  unique_sq_dist=U, traj_cap=64)
+    out = fit.run(g["R0"], g["T0"], 40)  # more steps enqueued than needed: the surplus must be no-ops
+    assert out["iterations"] == int(g["iterations"])
+    assert out["state"] == int(g["state"])
+    scale = max(1.0, np.abs(tgt).max())
+    np.testing.assert_allclose(out["R"], g["final_R"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(out["T"], g["final_T"], rtol=0, atol=1e-9 * scale)
+    n = len(g["traj"])
+    assert len(out["traj"]) == n
+    np.testing.assert_allclose(out["traj"][:, :12], g["traj"][:, :12], rtol=0, atol=1e-9 * scale)
+    np.testing.assert_allclose(out["traj"][:, 12], g["traj"][:, 12], rtol=1e-9)
+    assert (out["traj"][:, 13] == g["traj"][:, 13]).all()
+    # a second run on the same object starts from scratch (criteria state reset) and repeats itself bit for bit
+    again = fit.run(g["R0"], g["T0"], 40)
+    assert again["iterations"] == out["iterations"] and (again["R"] == out["R"]).all() and (again["T"] == out["T"]).all()
+
+
+def test_device_loop_is_bit_identical_to_host_loop(pcr, ctx):
+    """Same kernels, same reduction order, same solve source: the two loops must agree exactly."""
+    import torch
+    g, src, tgt, six, tix = _setup(pcr, ctx, "cube4096_k4")
+    U = float(g["uniq_tgt"])
+    part = torch.zeros(17, dtype=torch.float64, device="cuda")
+    R, T = g["R0"].copy(), g["T0"].copy()
+    host = []
+    for _ in range(6):
+        pcr.icp_step_d(ctx, six, tix, R, T, 4, U * 36, U * 4, part)
+        ctx.synchronize()
+        p = part.cpu().numpy()
+        pp, pq = pcr.icp_pivots(six, tix, R, T)
+        R, T, _, _, mse = pcr.solve_rigid(p, pp, pq, R, T)
+        host.append(np.concatenate([R, T, [mse, p[0]]]))
+    fit = pcr.Fit(ctx, six, tix, 4, U * 36, U * 4, conv=None, traj_cap=16)
+    out = fit.run(g["R0"], g["T0"], 6)
+    assert out["iterations"] == 6 and out["state"] == 0
+    assert (out["traj"] == np.array(host)).all()
+    assert (out["R"] == R).all() and (out["T"] == T).all()
+
+
+def test_device_loop_stops_without_correspondences(pcr, ctx):
+    g, src, tgt, six, tix = _setup(pcr, ctx, "patch_k1")
+    U = float(g["uniq_tgt"])
+    fit = pcr.Fit(ctx, six, tix, 1, U * 36, U * 4, conv=pcr.ConvergenceParams.regcfg(30), unique_sq_dist=U)
+    out = fit.run(np.eye(3).reshape(9), np.zeros(3), 5)  # the patches are 0.03 apart: nothing passes the gates
+    assert out["iterations"] == 1 and out["state"] == 5 and out["msg"] == "Criteria_NoCorrespondeces"
+    assert (out["R"] == np.eye(3).reshape(9)).all() and (out["T"] == 0).all()
+
+
+def test_device_loop_with_external_reduction(pcr, ctx):
+    """The multi-GPU hook: the caller reduces the 17 partials in place between step and solve.  Two half-range
+    fits whose partials are summed by hand must reproduce the full-range fit (pair counts exactly)."""
+    g, src, tgt, six, tix = _setup(pcr, ctx, "cube4096_k4")
+    U = float(g["uniq_tgt"])
+    n = len(src)
+    whole = pcr.Fit(ctx, six, tix, 4, U * 36, U * 4, traj_cap=8).run(g["R0"], g["T0"], 3)
+    a = pcr.Fit(ctx, six, tix, 4, U * 36, U * 4, sample_begin=0, m=n // 2, traj_cap=8)
+    b = pcr.Fit(ctx, six, tix, 4, U * 36, U * 4, sample_begin=n // 2, m=n - n // 2, traj_cap=8)
+    a.reset(g["R0"], g["T0"])
+    b.reset(g["R0"], g["T0"])
+    pa, pb = a.partials_tensor(), b.partials_tensor()
+    import torch
+    for _ in range(3):
+        a.step()
+        ctx.synchronize()      # the fixture's context has its own stream; torch works on another one
+        pa_mine = pa.clone()   # a and b share the source index's scratch: run them one after the other
+        b.step()
+        ctx.synchronize()
+        tot = pa_mine + pb     # what an all-reduce leaves on every rank
+        pa.copy_(tot)
+        pb.copy_(tot)
+        torch.cuda.synchronize()
+        a.solve()
+        b.solve()
+    ra, rb = a.read(), b.read()
+    assert (ra["R"] == rb["R"]).all() and (ra["T"] == rb["T"]).all()
+    assert (ra["traj"][:, 13] == whole["traj"][:, 13]).all()
+    np.testing.assert_allclose(ra["R"], whole["R"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(ra["T"], whole["T"], rtol=0, atol=1e-12)
