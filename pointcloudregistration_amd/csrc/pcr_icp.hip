@@ -14,7 +14,7 @@
 #include "knn_device.h"
 #include "solve_core.h"
 #ifndef PCR_STEP_WAVES
-#define PCR_STEP_WAVES 4
+#define PCR_STEP_WAVES 5
 #endif
 
 namespace pcr {
