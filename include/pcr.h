@@ -228,6 +228,9 @@ int pcr_fit_create(pcr_ctx *ctx, const pcr_index *src_index, const pcr_index *tg
                    const uint32_t *sample_idx_d /*nullable*/, uint32_t sample_begin, uint32_t m, uint32_t k,
                    double thr_fwd_sq, double thr_rev_sq, const pcr_convergence_params *conv /*nullable*/,
                    double unique_sq_dist, uint32_t traj_cap, pcr_fit **out);
+/* replace the sample set by a HOST list of source indices (copied; the fit owns the device copy).  An empty list
+ * (m = 0) yields zero sums.  Synchronises the stream. */
+int pcr_fit_set_samples(pcr_fit *fit, const uint32_t *sample_idx, uint32_t m);
 /* (re)start from the initial transform: iteration 0, criteria state as freshly constructed */
 int pcr_fit_reset(pcr_fit *fit, const double R[9], const double T[3]);
 int pcr_fit_enqueue_step(pcr_fit *fit);

@@ -74,6 +74,7 @@ SYMBOLS = {
     "pcr_icp_pivots": (C.c_int, [_vp, _vp, _dp, _dp, _dp, _dp]),
     "pcr_fit_create": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, _vp,
                                  C.c_double, C.c_uint32, C.POINTER(_vp)]),
+    "pcr_fit_set_samples": (C.c_int, [_vp, _up, C.c_uint32]),
     "pcr_fit_reset": (C.c_int, [_vp, _dp, _dp]),
     "pcr_fit_enqueue_step": (C.c_int, [_vp]),
     "pcr_fit_partials_d": (_vp, [_vp]),
@@ -327,6 +328,10 @@ class Fit:
                                     _vp(sample_idx_t.data_ptr()) if sample_idx_t is not None else None, sample_begin, m, k,
                                     thr_fwd_sq, thr_rev_sq, C.cast(C.byref(conv), _vp) if conv is not None else None,
                                     unique_sq_dist, traj_cap, C.byref(self.h)), "pcr_fit_create")
+
+    def set_samples(self, sample_idx):
+        a = np.ascontiguousarray(sample_idx, np.uint32)
+        _check(lib().pcr_fit_set_samples(self.h, _u(a), len(a)), "pcr_fit_set_samples")
 
     def reset(self, R, T):
         R, T = _rt(R, T)

@@ -458,6 +458,7 @@ struct pcr_fit {
     double *partials_d;   // [17]
     double *block_partials_d;
     double *traj_d;       // [traj_cap][14]
+    uint32_t *samples_d;  // owned copy of a host sample list (pcr_fit_set_samples)
     FitDev init;          // host-side template of the state (reset copies it)
 };
 
@@ -682,6 +683,7 @@ int pcr_fit_destroy(pcr_fit *f) {
     if (f->partials_d) hipFree(f->partials_d);
     if (f->block_partials_d) hipFree(f->block_partials_d);
     if (f->traj_d) hipFree(f->traj_d);
+    if (f->samples_d) hipFree(f->samples_d);
     delete f;
     return PCR_OK;
 }
@@ -735,6 +737,32 @@ int pcr_fit_create(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
         return rc;
     }
     *out = f;
+    return PCR_OK;
+}
+
+int pcr_fit_set_samples(pcr_fit *f, const uint32_t *sample_idx, uint32_t m) {
+    PCR_REQUIRE(f && (sample_idx || m == 0), "pcr_fit_set_samples: NULL argument");
+    for (uint32_t i = 0; i < m; ++i)
+        PCR_REQUIRE(sample_idx[i] < f->src->n, "pcr_fit_set_samples: sample_idx[%u]=%u out of range", i, sample_idx[i]);
+    PCR_HIP(hipSetDevice(f->ctx->device));
+    PCR_HIP(hipStreamSynchronize(f->ctx->stream));  // nothing in flight may still read the old list or partials
+    if (f->samples_d) hipFree(f->samples_d);
+    f->samples_d = nullptr;
+    const uint32_t nb = m ? (m + 255) / 256 : 0;
+    if (nb > f->nb) {
+        hipFree(f->block_partials_d);
+        f->block_partials_d = nullptr;
+        PCR_HIP(hipMalloc(&f->block_partials_d, sizeof(double) * 17 * (size_t)nb));
+        f->args.block_partials = f->block_partials_d;
+    }
+    if (m) {
+        PCR_HIP(hipMalloc(&f->samples_d, sizeof(uint32_t) * (size_t)m));
+        PCR_HIP(hipMemcpy(f->samples_d, sample_idx, sizeof(uint32_t) * (size_t)m, hipMemcpyHostToDevice));
+    }
+    f->args.sample_idx = f->samples_d;
+    f->args.sample_begin = 0;
+    f->args.m = m;
+    f->nb = nb;
     return PCR_OK;
 }
 

@@ -1,4 +1,5 @@
 #include "iterative_fit.h"
+#include <algorithm>
 #include <cmath>
 #include <limits>
 
@@ -137,7 +138,7 @@ std::tuple<Eigen::Matrix3d, ColVector3, std::string> CIterativeFit::fit(const hi
         hiveEventLogger::hiveOutputWarning(__EXCEPTION_SITE__, "control point cannot be less than 5.");
         return std::make_tuple(Rot, Tra, std::string("Point Cloud Not Valid!"));  // (:86)
     }
-    __fitLoop(Rot, Tra);
+    if (!__fitLoopFused(Rot, Tra)) __fitLoop(Rot, Tra);
     return std::make_tuple(Rot, Tra, m_pConvergenceCriterial->getConvergenceMsg());
 }
 
@@ -162,6 +163,88 @@ void CIterativeFit::__fitLoop(Eigen::Matrix3d &vioR, ColVector3 &vioT) {
     while (FIT_END != _fitStepV(++IterationCounter, vioR, vioT)) {
     }
     m_NumIterations = IterationCounter;
+}
+
+// The same loop with nothing but the final (R,T) leaving the device: possible when every stage is the GPU default
+// (closest-points estimation, pass-through rejection, SVD2, default criteria) and the samples are indices into the
+// source cloud.  Same iteration count, state and -- bit for bit -- transform as the stage-by-stage path.
+// false: not applicable (the caller then runs __fitLoop).
+bool CIterativeFit::__fitLoopFused(Eigen::Matrix3d &vioR, ColVector3 &vioT) {
+    int Fused = 1;
+    PTR_CONTROL_PARAMS->dumpValue(getKeyFusedLoop(), Fused);
+    pcrhost::CDeviceSession *pSession = pcrhost::CDeviceSession::getInstance();
+    if (!Fused || pSession->world() > 1) return false;  // sharded runs reduce through the host hook, stage by stage
+    if (!dynamic_cast<CCorrespondenceEstimationClosestPointsGPU *>(m_pCorrespondenceEstimation) ||
+        !dynamic_cast<CCorrespondenceRejectionClosestPoints *>(m_pCorrespondenceRejection) ||
+        !dynamic_cast<CTransformationEstimationSVD2GPU *>(m_pTransformationEsitmation))
+        return false;
+    const CIndexSubset *pSamples = dynamic_cast<const CIndexSubset *>(m_SampleSubset.get());
+    if (!pSamples || &pSamples->getPointCloud() != m_pSourcePointCloud) return false;
+    const pcrhost::SDeviceCloud *pSrc = pSession->acquire(m_pSourcePointCloud), *pTgt = pSession->acquire(m_pTargetPointCloud);
+    if (!pSrc || !pTgt) return false;  // the stage-by-stage path reports the failure
+
+    CControlParameters *pConfig = PTR_CONTROL_PARAMS;
+    unsigned int NumNeighbors = 4;
+    double SDFT = 36.0, NDFT = 4.0;
+    pConfig->dumpValue(CCorrespondenceEstimationClosestPointsGPU::getKeyNumNeighbors(), NumNeighbors);
+    pConfig->dumpValue(CCorrespondenceEstimationClosestPointsGPU::getKeySquareDistFactorThreshold(), SDFT);
+    pConfig->dumpValue(CCorrespondenceEstimationClosestPointsGPU::getKeyNeighbourDistFactorThreshold(), NDFT);
+    pcr_convergence_params Conv;
+    Conv.max_iterations = 1000;
+    bool FAMI = false;
+    Conv.rotation_threshold = Conv.translation_threshold = Conv.abs_mse = Conv.rel_mse = 0.0;
+    Conv.max_similar = 0;
+    pConfig->dumpValue(CBaseConvergenceCriteria::getKeyMaxIterations(), Conv.max_iterations);
+    pConfig->dumpValue(CDefaultConvergenceCriteria::getKeyFailureAfterMaxIterations(), FAMI);
+    pConfig->dumpValue(CDefaultConvergenceCriteria::getKeyRotationThreshold(), Conv.rotation_threshold);
+    pConfig->dumpValue(CDefaultConvergenceCriteria::getKeyTranslationThreshold(), Conv.translation_threshold);
+    pConfig->dumpValue(CDefaultConvergenceCriteria::getKeyAbsoluteMSE(), Conv.abs_mse);
+    pConfig->dumpValue(CDefaultConvergenceCriteria::getKeyRelativeMSE(), Conv.rel_mse);
+    pConfig->dumpValue(CDefaultConvergenceCriteria::getKeyMaxIterationSimilarTransforms(), Conv.max_similar);
+    Conv.failure_after_max_iterations = FAMI ? 1 : 0;
+    const double UniqueSquareDist = product<CUniqueData>(CUniqueData::getSigTgtUniqueData())->getUniqSquareDist();
+
+    const std::vector<unsigned int> &Indices = pSamples->getIndexSet();
+    bool Identity = Indices.size() == pSrc->NumPoints;
+    for (size_t i = 0; Identity && i < Indices.size(); ++i) Identity = Indices[i] == i;
+    // with FAMI the reference iterates past MI until another test fires (possibly for ever): bounded here
+    const unsigned int Budget = FAMI ? 4 * Conv.max_iterations + 64 : Conv.max_iterations;
+    const unsigned int TrajCap = m_Observer ? Budget : 0;
+    pcr_fit *pFit = NULL;
+    int Status = pcr_fit_create(pSession->context(), pSrc->pIndex, pTgt->pIndex, NULL, 0, Identity ? pSrc->NumPoints : 0u,
+                                NumNeighbors, UniqueSquareDist * SDFT, UniqueSquareDist * NDFT, &Conv, UniqueSquareDist,
+                                TrajCap, &pFit);
+    if (Status == PCR_OK && !Identity) Status = pcr_fit_set_samples(pFit, Indices.data(), (uint32_t)Indices.size());
+    if (Status == PCR_OK) Status = pcr_fit_reset(pFit, vioR.data(), vioT.data());
+    uint32_t Iterations = 0;
+    int State = PCR_FIT_NOT_CONVERGED;
+    unsigned int Enqueued = 0;
+    while (Status == PCR_OK) {
+        // a batch of iterations without the host in between; once the criteria fire the rest of a batch is no-ops
+        const unsigned int Batch = std::min(16u, Budget - Enqueued);
+        for (unsigned int i = 0; i < Batch && Status == PCR_OK; ++i) {
+            Status = pcr_fit_enqueue_step(pFit);
+            if (Status == PCR_OK) Status = pcr_fit_enqueue_solve(pFit);
+        }
+        Enqueued += Batch;
+        if (Status == PCR_OK) Status = pcr_fit_read(pFit, vioR.data(), vioT.data(), &Iterations, &State, NULL, NULL, NULL, 0);
+        if (Iterations < Enqueued || Enqueued >= Budget) break;  // stopped by itself, or out of budget
+    }
+    if (Status == PCR_OK && m_Observer && Iterations) {
+        std::vector<double> Traj((size_t)Iterations * 14);
+        if (pcr_fit_read(pFit, NULL, NULL, NULL, NULL, NULL, NULL, Traj.data(), Iterations) == PCR_OK)
+            for (uint32_t i = 0; i < Iterations && i < TrajCap; ++i)
+                m_Observer(i + 1, &Traj[(size_t)i * 14], &Traj[(size_t)i * 14 + 9], Traj[(size_t)i * 14 + 12],
+                           (unsigned int)Traj[(size_t)i * 14 + 13], m_ObserverUser);
+    }
+    if (pFit) pcr_fit_destroy(pFit);
+    if (Status != PCR_OK) {
+        hiveEventLogger::hiveOutputWarning(__EXCEPTION_SITE__, std::string("device-resident loop: ") + pcr_strerror(Status) + " -- " + pcr_last_error());
+        return false;
+    }
+    m_NumIterations = Iterations;
+    pConfig->set(CBaseConvergenceCriteria::getKeyConvergenceState(), State < 0 ? 0 : State);
+    return true;
 }
 
 CIterativeFit::EFitFlag CIterativeFit::_fitStepV(unsigned int vIterationCounter, Eigen::Matrix3d &vioR, ColVector3 &vioT) {

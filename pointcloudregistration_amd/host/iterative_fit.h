@@ -67,6 +67,9 @@ private:
 class CIterativeFit {
 public:
     static std::string getKeySamplePointCloud() { return toUpperCopy("IterativeFit.SPC"); }
+    // no reference counterpart: 1 (default) lets fit() run the whole loop device-resident (pcr_fit_*) when every
+    // stage is the GPU default; 0 forces the stage-by-stage path through the plugin interfaces
+    static std::string getKeyFusedLoop() { return toUpperCopy("IterativeFit.FusedLoop"); }
 
     CIterativeFit()
         : m_pSourcePointCloud(NULL), m_pTargetPointCloud(NULL), m_pPointSampler(NULL), m_pCorrespondenceEstimation(NULL),
@@ -122,6 +125,7 @@ private:
 
     void __setMethodPointCloud();
     void __fitLoop(Eigen::Matrix3d &vioR, ColVector3 &vioT);
+    bool __fitLoopFused(Eigen::Matrix3d &vioR, ColVector3 &vioT);
     void __setPointCloud(const hivePointCloud::CPointCloud &vSourcePointCloud, const hivePointCloud::CPointCloud &vTargetPointCloud);
 };
 
