@@ -167,6 +167,53 @@ __device__ __forceinline__ double box_bound2(const GridView &g, double sx, doubl
     return b2;
 }
 
+// A long candidate range (a row of cells through a dense part of the cloud).  Rows are sorted by grid-frame x
+// (pcr_sort.hip), so instead of scanning all of it the lane enters at the query's x by binary search and walks
+// outwards in both directions, stopping a direction as soon as the x-gap alone -- shrunk by the safety margin and
+// the bound scale -- exceeds the current K-th distance: everything beyond is farther still.  Exact for the same
+// reason every other pruning here is: the test is strict, and `wd` only ever shrinks.
+//   order: the grid-frame points the range is sorted by (g.pts); cand: what distances are evaluated against
+//   (g.pts again, or the transformed copy for the reverse search of the ICP step).
+#define PCR_LONG_RANGE 48u
+template <int KC>
+__device__ __forceinline__ void windowed_scan(const Pt4 *__restrict__ order, const Pt4 *__restrict__ cand, uint32_t b,
+                                              uint32_t e, double qx, double qy, double qz, double sx, double margin,
+                                              double bound_scale, TopK<KC> &top, double &wd, uint32_t &wi) {
+    uint32_t lo = b, hi = e;
+    while (lo < hi) {  // first position with x >= sx
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (order[mid].x < sx)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    for (uint32_t i = lo; i < e; ++i) {
+        const double gap = order[i].x - sx - margin;
+        if ((gap > 0.0) & (gap * gap * bound_scale > wd)) break;
+        const Pt4 c = cand[i];
+        const double d = sqdist3(qx, qy, qz, c.x, c.y, c.z);
+        const uint32_t ci = (uint32_t)c.w;
+        if (better(d, ci, wd, wi)) {
+            top.insert(d, ci);
+            wd = top.worst_d();
+            wi = top.worst_i();
+        }
+    }
+    for (uint32_t i = lo; i > b;) {
+        --i;
+        const double gap = sx - order[i].x - margin;
+        if ((gap > 0.0) & (gap * gap * bound_scale > wd)) break;
+        const Pt4 c = cand[i];
+        const double d = sqdist3(qx, qy, qz, c.x, c.y, c.z);
+        const uint32_t ci = (uint32_t)c.w;
+        if (better(d, ci, wd, wi)) {
+            top.insert(d, ci);
+            wd = top.worst_d();
+            wi = top.worst_i();
+        }
+    }
+}
+
 // Exact K-NN of one query on the grid.
 //   cand     : candidate coordinates, parallel to g.pts (g.pts itself for a plain search, the
 //              transformed copy for the reverse search of the ICP step)
@@ -179,7 +226,7 @@ __device__ __forceinline__ double box_bound2(const GridView &g, double sx, doubl
 //   max_d2   : candidates with d2 >= max_d2 are of no interest; the search may stop as soon as every
 //              unvisited point is at least that far
 // top must be initialised by the caller (init(), or pre-seeded with a known candidate).
-template <int KC>
+template <int KC, bool WINDOW = true>
 __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__restrict__ cand, double qx, double qy,
                                             double qz, double sx, double sy, double sz, double max_d2,
                                             double bound_scale, double extra_margin, TopK<KC> &top,
@@ -215,7 +262,11 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
         pz1 = min(cz + (r_start - 1), gz - 1);
     }
     const int rmax = max(max(gx, gy), gz);
-    for (int r = r_start; r <= rmax; ++r) {
+    // Shell radius: not one ring at a time.  Once K candidates are known, everything that can still matter lies
+    // within sqrt(wd) of the query, so the NEXT shell is made thick enough to cover that at once; while fewer than
+    // K are known the radius doubles.  A query far from the data (an outlier in empty space) thus costs one or a
+    // few box scans instead of hundreds of shells whose inner rows are re-opened every time.
+    for (int r = r_start; r <= rmax;) {
         const int x0 = max(cx - r, 0), x1 = min(cx + r, gx - 1);
         const int y0 = max(cy - r, 0), y1 = min(cy + r, gy - 1);
         const int z0 = max(cz - r, 0), z1 = min(cz + r, gz - 1);
@@ -249,6 +300,12 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
                     const size_t base = ((size_t)rz * gy + ry) * gx;
                     p = cs[base + xs];
                     e = cs[base + xe + 1];
+                    if constexpr (WINDOW) {
+                        if (e - p > PCR_LONG_RANGE && e > p) {  // dense stretch: enter at the query's x instead
+                            windowed_scan<KC>(g.pts, cand, p, e, qx, qy, qz, sx, margin, bound_scale, top, wd, wi);
+                            p = e;
+                        }
+                    }
                 }
                 if (advance) {
                     ++row;
@@ -282,6 +339,16 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
         py1 = y1;
         pz0 = z0;
         pz1 = z1;
+        const double reach2 = fmin(wd, max_d2);  // nothing at or beyond this squared distance can matter
+        int rn = r + 1;
+        if (reach2 < PCR_INF) {
+            const double cells_needed = (sqrt(reach2 / bound_scale) + margin) * g.inv_h + 2.0;
+            const int need = cells_needed < (double)rmax ? (int)cells_needed : rmax;
+            rn = wd < PCR_INF ? max(rn, need) : max(rn, min(2 * r, need));
+        } else {
+            rn = max(rn, 2 * r);
+        }
+        r = min(rn, rmax);  // at r == rmax the box is the whole grid and the loop ends through `all`
     }
 }
 
@@ -364,6 +431,10 @@ __device__ __forceinline__ bool ring1_pruned(const GridView &g, const Pt4 *__res
                 const uint32_t xe = has_xh & !(wd < gyz + gxh) ? row.y + 2u : row.y + 1u;
                 p = cs[xs];
                 e = cs[xe];
+                if (e - p > PCR_LONG_RANGE && e > p) {  // dense stretch: enter at the query's x instead
+                    windowed_scan<KC>(g.pts, cand, p, e, qx, qy, qz, sx, margin, bound_scale, top, wd, wi);
+                    p = e;
+                }
             }
         }
         if (p < e) {
@@ -414,7 +485,7 @@ __device__ __forceinline__ void lane_search(const GridView &g, const Pt4 *__rest
     const bool fin1 = ring1_pruned<KC>(g, cand, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, rowtab);
     DIAG_LANE_ADD(8 * (KC == 1) + 6, fin1 ? 0 : 1);  // lanes continuing with ring 2
     if (!fin1)
-        grid_search<KC>(g, cand, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, 2);
+        grid_search<KC, false>(g, cand, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, 2);
 }
 
 // Brute-force scan of one LDS tile (all lanes read the same address: LDS broadcast).

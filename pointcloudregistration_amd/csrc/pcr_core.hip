@@ -181,20 +181,23 @@ __global__ void __launch_bounds__(256) scatter_kernel(const double *__restrict__
     }
 }
 
-// The scatter's atomics leave the order inside a cell to chance.  It cannot change a result (the
-// search orders candidates by (d2, index)), but a fixed layout makes runs reproducible to the byte:
-// order every cell by original index (cells are tiny; huge degenerate cells are left as they are).
+// The scatter's atomics leave the order inside a cell to chance.  Every cell is put into a fixed order -- by x,
+// ties by original index -- for two reasons: runs become reproducible to the byte, and a (y,z) row of cells is
+// then sorted by x as a whole, which lets the search window long rows (knn_device.h, windowed_scan).  One thread
+// per small cell here; cells above PCR_HEAVY_CELL points go through the segmented sort (pcr_sort.hip).
 __global__ void __launch_bounds__(256) cell_order_kernel(const uint32_t *__restrict__ cs, uint64_t cells,
                                                          Pt4 *__restrict__ pts) {
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= cells) return;
     const uint32_t b = cs[c], e = cs[c + 1];
-    if (e - b < 2 || e - b > 256) return;
+    if (e - b < 2 || e - b > PCR_HEAVY_CELL) return;
     for (uint32_t i = b + 1; i < e; ++i) {
         const Pt4 v = pts[i];
         uint32_t j = i;
-        while (j > b && (uint32_t)pts[j - 1].w > (uint32_t)v.w) {
-            pts[j] = pts[j - 1];
+        while (j > b) {
+            const Pt4 u = pts[j - 1];
+            if (!((u.x > v.x) | ((u.x == v.x) & ((uint32_t)u.w > (uint32_t)v.w)))) break;
+            pts[j] = u;
             --j;
         }
         pts[j] = v;
@@ -943,6 +946,10 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
                                cursor_d, ix->pts_d);
             hipLaunchKernelGGL(cell_order_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream,
                                counts_d, cells, ix->pts_d);
+            if (stats_h[1] > PCR_HEAVY_CELL) {
+                rc = sort_heavy_cells(ctx, counts_d, cells, n, ix->pts_d, ix->tpts_d);
+                if (rc != PCR_OK) goto fail;
+            }
             hipLaunchKernelGGL(pos_of_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ix->pts_d, n,
                                ix->pos_of_d);
             BUILD_HIP(hipStreamSynchronize(ctx->stream));

@@ -112,6 +112,10 @@ void *ctx_scratch(pcr_ctx *ctx, int slot, size_t bytes);
 // pts / xyz_aos is non-NULL.  deterministic: order inside a brick made ascending (index build only).
 int brick_order(pcr_ctx *ctx, const GridView &g, const Pt4 *pts, const double *xyz_aos, uint32_t n,
                 uint32_t *order_d, bool deterministic);
+// cells above this many points are ordered by the segmented sort (pcr_sort.hip), the others by one thread each
+#define PCR_HEAVY_CELL 32u
+// orders the points of every heavy cell by (x, original index); tmp is scratch of the same size as pts
+int sort_heavy_cells(pcr_ctx *ctx, const uint32_t *cs_d, uint64_t cells, uint32_t n, Pt4 *pts, Pt4 *tmp);
 // positions [0,nq) of a query batch grouped by the top bits of a Morton key (fast, not deterministic inside a group)
 int coarse_query_order(pcr_ctx *ctx, const GridView &g, const double *q_d, uint32_t nq, uint32_t *order_d);
 }  // namespace pcr

@@ -85,8 +85,9 @@ def lidar_like(n, seed, outlier_frac=0.0, extent=(200.0, 200.0, 30.0)):
     from a sensor at the origin; a fraction of points replaced by uniform-in-volume outliers."""
     rng = np.random.default_rng(seed)
     ex, ey, ez = extent
-    # range-dependent density: r ~ sqrt(uniform) concentrates samples near the sensor
-    r = np.sqrt(rng.random(n)) * 0.5 * min(ex, ey)
+    # range-dependent density ~ 1/r^2 from the sensor: r log-uniform between 1 m and the half extent
+    rmax = 0.5 * min(ex, ey)
+    r = np.exp(rng.random(n) * np.log(rmax))
     th = rng.random(n) * 2 * np.pi
     p = np.stack([r * np.cos(th), r * np.sin(th), np.zeros(n)], 1)
     # a third of the points climb the walls of axis-aligned boxes on a 25 m lattice
@@ -100,6 +101,22 @@ def lidar_like(n, seed, outlier_frac=0.0, extent=(200.0, 200.0, 30.0)):
         k = int(m.sum())
         p[m] = (rng.random((k, 3)) - [0.5, 0.5, 0.0]) * [ex, ey, ez]
     return np.ascontiguousarray(p)
+
+
+def lidar_pair(n, seed, outlier_frac=0.3, rot_deg=(0.4, -0.3, 1.5), trans=(0.35, -0.2, 0.05), noise=0.01):
+    """C5: two LiDAR-like scans of the same scene, the source moved by the inverse of a known
+    small rigid motion (a vehicle's step between two sweeps) + Gaussian range noise; `outlier_frac` of the SOURCE
+    points are uniform-in-volume outliers.  Returns (src, tgt, R_true, t_true) with tgt ~= R_true*src + t_true."""
+    tgt = lidar_like(n, seed, 0.0)
+    s = lidar_like(n, seed + 1, 0.0)
+    rng = np.random.default_rng(seed + 2)
+    s += rng.standard_normal(s.shape) * noise
+    Rm, t = euler_zyx(*rot_deg), np.asarray(trans, np.float64)
+    src = (s - t) @ Rm
+    if outlier_frac > 0:
+        m = rng.random(n) < outlier_frac
+        src[m] = (rng.random((int(m.sum()), 3)) - [0.5, 0.5, 0.0]) * [200.0, 200.0, 30.0]
+    return np.ascontiguousarray(src), tgt, Rm, t
 
 
 def coarse_initial_transform(R_true, t_true, n, rot_spacings=1.5, trans_spacings=1.0):
