@@ -241,6 +241,20 @@ int pcr_fit_read(pcr_fit *fit, double R[9], double T[3], uint32_t *iterations, i
                  double *pairs, double *traj, uint32_t traj_rows);
 int pcr_fit_destroy(pcr_fit *fit);
 
+/* ---- the exchange step of the multi-GPU loop ---------------------------------------------------
+ * No reference counterpart (the reference is a single-threaded CPU program).  One process per GPU, samples
+ * sharded, clouds and indices replicated; the only exchange per iteration is the sum of the 17 partials.
+ * pcr_allreduce_partials enqueues an in-place RCCL all-reduce of 17 doubles on the context's stream (between
+ * pcr_fit_enqueue_step and pcr_fit_enqueue_solve, or after pcr_icp_step_d).  RCCL is bound at run time; without
+ * it these return PCR_E_UNSUPPORTED.  Rank 0 creates the id and distributes it out of band (a file, MPI, a socket);
+ * pcr_comm_create is collective.  A caller that already owns a communicator may all-reduce the buffer itself. */
+#define PCR_COMM_ID_BYTES 128
+typedef struct pcr_comm pcr_comm;
+int pcr_comm_unique_id(char id[PCR_COMM_ID_BYTES]);
+int pcr_comm_create(pcr_ctx *ctx, int rank, int world, const char id[PCR_COMM_ID_BYTES], pcr_comm **out);
+int pcr_allreduce_partials(pcr_comm *comm, double *partials_d);
+int pcr_comm_destroy(pcr_comm *comm);
+
 /* ---- host: CTransformationEstimationSVD2::__computeRelativeRotationAndTranslation
  *      (TransformationEstimationSVD2.cpp:98-117) + accumulateTransformation
  *      (BaseTransformationEstimation.h:28-32), fed by the 17 partials instead of pair lists.

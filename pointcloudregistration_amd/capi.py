@@ -81,6 +81,10 @@ SYMBOLS = {
     "pcr_fit_enqueue_solve": (C.c_int, [_vp]),
     "pcr_fit_read": (C.c_int, [_vp, _dp, _dp, _up, C.POINTER(C.c_int), _dp, _dp, _dp, C.c_uint32]),
     "pcr_fit_destroy": (C.c_int, [_vp]),
+    "pcr_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "pcr_comm_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p, C.POINTER(_vp)]),
+    "pcr_allreduce_partials": (C.c_int, [_vp, _vp]),
+    "pcr_comm_destroy": (C.c_int, [_vp]),
     "pcr_reduce_pairs": (C.c_int, [_vp, _dp, _dp, C.c_uint32, _dp, _dp, _dp]),
     "pcr_solve_rigid": (C.c_int, [_dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "pcr_reject_centroid_dist": (C.c_int, [_vp, _vp, _vp, _dp, _dp, C.c_uint32, C.c_uint32, C.c_double, C.c_double,
@@ -161,7 +165,7 @@ class Context:
 
     def close(self):
         if self.h:
-            for cls in (Fit, Index, Cloud):  # dependants first, in dependency order
+            for cls in (Comm, Fit, Index, Cloud):  # dependants first, in dependency order
                 for child in [c for c in self._children if isinstance(c, cls)]:
                     child.close()
             lib().pcr_ctx_destroy(self.h)
@@ -376,6 +380,38 @@ class Fit:
     def close(self):
         if self.h:
             lib().pcr_fit_destroy(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm:
+    """pcr_comm: RCCL communicator bound to a context's stream (one process per GPU)."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _check(lib().pcr_comm_unique_id(buf), "pcr_comm_unique_id")
+        return buf.raw
+
+    def __init__(self, ctx, rank, world, uid):
+        self.ctx = ctx
+        self.h = _vp()
+        ctx._children.add(self)
+        _check(lib().pcr_comm_create(ctx.h, rank, world, uid, C.byref(self.h)), "pcr_comm_create")
+
+    def allreduce_partials(self, ptr):
+        """ptr: device address (int) or a CUDA tensor of >= 17 float64."""
+        addr = ptr.data_ptr() if hasattr(ptr, "data_ptr") else int(ptr)
+        _check(lib().pcr_allreduce_partials(self.h, _vp(addr)), "pcr_allreduce_partials")
+
+    def close(self):
+        if self.h:
+            lib().pcr_comm_destroy(self.h)
             self.h = _vp()
 
     def __del__(self):

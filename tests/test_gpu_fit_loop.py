@@ -99,3 +99,18 @@ def test_device_loop_with_external_reduction(pcr, ctx):
     assert (ra["traj"][:, 13] == whole["traj"][:, 13]).all()
     np.testing.assert_allclose(ra["R"], whole["R"], rtol=0, atol=1e-12)
     np.testing.assert_allclose(ra["T"], whole["T"], rtol=0, atol=1e-12)
+
+
+def test_rccl_allreduce_entry_point_single_rank(pcr, ctx):
+    """pcr_comm_* / pcr_allreduce_partials with a one-rank communicator (the box has one GPU): the in-place
+    all-reduce between step and solve must leave the fit bit-identical to the loop without it.  N > 1 runs the
+    same call with more ranks (bench.py uses torch.distributed's RCCL communicator for that)."""
+    g, src, tgt, six, tix = _setup(pcr, ctx, "cube4096_k4")
+    U = float(g["uniq_tgt"])
+    comm = pcr.Comm(ctx, 0, 1, pcr.Comm.unique_id())
+    fit = pcr.Fit(ctx, six, tix, 4, U * 36, U * 4, traj_cap=8)
+    plain = fit.run(g["R0"], g["T0"], 4)
+    ptr = pcr.lib().pcr_fit_partials_d(fit.h)
+    out = fit.run(g["R0"], g["T0"], 4, all_reduce=lambda _t: comm.allreduce_partials(ptr))
+    assert (out["traj"] == plain["traj"]).all() and (out["R"] == plain["R"]).all()
+    comm.close()
