@@ -102,6 +102,12 @@ def main():
     ap.add_argument("--no-knn", action="store_true")
     args = ap.parse_args()
 
+    # Libraries underneath (RCCL prints a version banner) write to stdout; the contract is ONE JSON line there.
+    # Everything but that line goes to stderr: fd 1 is pointed at fd 2 until the result is printed.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from pointcloudregistration_amd import capi, synth
@@ -110,8 +116,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # PCR_BENCH_FORCE_DIST=1: run the collective path on a single rank too (rehearsal of the N > 1 code on one GPU)
+    force_dist = os.environ.get("PCR_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node = --gpus"
@@ -154,13 +163,13 @@ def main():
     def enqueue(steps):
         for _ in range(steps):
             fit.step()
-            if world > 1:
+            if world > 1 or force_dist:
                 dist.all_reduce(part_t)
             fit.solve()
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -240,8 +249,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(src, tgt, R0, T0, k, sdft, ndft)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 
