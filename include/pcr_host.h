@@ -63,6 +63,18 @@ int pcrh_svd2(const double *pair_a, const double *pair_b, uint32_t P, double R[9
 int pcrh_search(const double *points, uint32_t n, uint32_t dim, const double *queries, uint32_t nq, uint32_t k, int nearest_first,
                 int multi_threaded, uint32_t *out_idx);
 
+/* ASCII PLY as the reference reads and writes it (PLYLoad.cpp:76-111, unit test/TestUnitity.cpp:278-339): `x y z`
+ * (+ `nx ny nz` with_normals) per vertex after `element vertex N` ... `end_header`; faces ignored.
+ * pcrh_ply_load: -1 unreadable, -3 more than `cap` vertices (out_n still holds the count: call again). */
+int pcrh_ply_load(const char *path, int with_normals, uint32_t cap, double *out_xyz, double *out_normals, uint32_t *out_n);
+int pcrh_ply_save(const char *path, const double *xyz, const double *normals /*nullable*/, uint32_t n);
+
+/* CRegistartion::fineFit (Registration.cpp:144-158) over a scan sequence: scan i+1 is registered to scan i from
+ * init_RT[i] = {R[9], T[3]} (NULL: identity).  out_relative_RT[i] maps scan i+1 into scan i's frame,
+ * out_absolute_RT[i] into scan 0's; out_iterations[i], msgs + i*msg_stride: per pair.  num_scans >= 2. */
+int pcrh_register_sequence(const double *const *scans, const uint32_t *counts, uint32_t num_scans, const double *init_RT,
+                           double *out_relative_RT, double *out_absolute_RT, uint32_t *out_iterations, char *msgs, uint32_t msg_stride);
+
 /* CDefaultConvergenceCriteria on explicit pair lists (host only; DefaultConvergenceCriterial.cpp:69-207).
  * pcrh_conv_reset clears the criteria's carried state and sets the target's unit square distance. */
 void pcrh_conv_reset(double target_unique_sq_dist);

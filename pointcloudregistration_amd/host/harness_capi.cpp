@@ -8,6 +8,8 @@
 #include <vector>
 #include "iterative_fit.h"
 #include "pcr_host.h"
+#include "ply_io.h"
+#include "registration.h"
 #include "search_plugin.h"
 
 using namespace hiveRegistration;
@@ -198,6 +200,64 @@ int pcrh_search(const double *points, uint32_t n, uint32_t dim, const double *qu
     if (SizeOk && out_idx) std::memcpy(out_idx, pResult->data(), sizeof(uint32_t) * pResult->size());
     delete pResult;  // owned by the caller (BaseSearch.cpp:48-53)
     return SizeOk ? 0 : -3;
+}
+
+int pcrh_ply_load(const char *path, int with_normals, uint32_t cap, double *out_xyz, double *out_normals, uint32_t *out_n) {
+    hivePointCloud::CPointCloud Cloud;
+    if (!path || !hivePointCloud::plyLoadFile(path, Cloud, with_normals ? 3 : 0)) return -1;
+    const uint32_t N = Cloud.getNumPoints();
+    if (out_n) *out_n = N;
+    if (N > cap) return -3;
+    if (out_xyz) std::memcpy(out_xyz, Cloud.getPosPointer(), sizeof(double) * 3 * N);
+    if (out_normals && Cloud.getNormalPointer()) std::memcpy(out_normals, Cloud.getNormalPointer(), sizeof(double) * 3 * N);
+    return 0;
+}
+
+int pcrh_ply_save(const char *path, const double *xyz, const double *normals, uint32_t n) {
+    if (!path || !xyz) return -1;
+    hivePointCloud::CPointCloud Cloud;
+    fillCloud(Cloud, xyz, normals, n);
+    return export2Ply(path, Cloud) ? 0 : -1;
+}
+
+int pcrh_register_sequence(const double *const *scans, const uint32_t *counts, uint32_t num_scans, const double *init_RT,
+                           double *out_relative_RT, double *out_absolute_RT, uint32_t *out_iterations, char *msgs, uint32_t msg_stride) {
+    if (!scans || !counts || num_scans < 2) return -1;
+    std::vector<hivePointCloud::CPointCloud> Clouds(num_scans);
+    std::vector<const hivePointCloud::CPointCloud *> Ptrs(num_scans);
+    for (uint32_t i = 0; i < num_scans; ++i) {
+        Clouds[i].setPos(scans[i], counts[i]);
+        Ptrs[i] = &Clouds[i];
+    }
+    std::vector<CRegistartion::SPose> Init, Rel, Abs;
+    if (init_RT)
+        for (uint32_t i = 0; i + 1 < num_scans; ++i) {
+            CRegistartion::SPose P;
+            std::memcpy(P.R.data(), init_RT + (size_t)i * 12, 72);
+            std::memcpy(P.T.data(), init_RT + (size_t)i * 12 + 9, 24);
+            Init.push_back(P);
+        }
+    if (CSamplerIndexList *pSampler = dynamic_cast<CSamplerIndexList *>(
+            hiveCommon::CProductFactoryData::getInstance()->getOrCreateProduct(CSamplerIndexList::getClassSig())))
+        pSampler->setIndexList(std::vector<unsigned int>());  // every point of each source scan
+    CRegistartion Registration;
+    Registration.registerSequence(Ptrs, Init, Rel, Abs);
+    for (uint32_t i = 0; i + 1 < num_scans && i < Rel.size(); ++i) {
+        if (out_relative_RT) {
+            std::memcpy(out_relative_RT + (size_t)i * 12, Rel[i].R.data(), 72);
+            std::memcpy(out_relative_RT + (size_t)i * 12 + 9, Rel[i].T.data(), 24);
+        }
+        if (out_absolute_RT) {
+            std::memcpy(out_absolute_RT + (size_t)i * 12, Abs[i + 1].R.data(), 72);
+            std::memcpy(out_absolute_RT + (size_t)i * 12 + 9, Abs[i + 1].T.data(), 24);
+        }
+        if (out_iterations) out_iterations[i] = Rel[i].Iterations;
+        if (msgs && msg_stride) copyMsg(Rel[i].Msg, msgs + (size_t)i * msg_stride, msg_stride);
+    }
+    hiveCommon::CProductFactoryData::getInstance()->releaseProduct(CCorrespondenceEstimationClosestPointsGPU::getClassSig());
+    hiveCommon::CProductFactoryData::getInstance()->releaseProduct(CRejectionCentroidDistGPU::getClassSig());
+    hiveCommon::CProductFactoryData::getInstance()->releaseProduct(CCorrespondenceRejectionClosestPoints::getClassSig());
+    return Rel.size() + 1 == num_scans ? 0 : -2;
 }
 
 /* host-only: CDefaultConvergenceCriteria driven with explicit pair lists */

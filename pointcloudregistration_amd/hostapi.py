@@ -29,6 +29,9 @@ SYMBOLS = {
                                        C.c_uint32, _up]),
     "pcrh_svd2": (C.c_int, [_dp, _dp, C.c_uint32, _dp, _dp]),
     "pcrh_search": (C.c_int, [_dp, C.c_uint32, C.c_uint32, _dp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, _up]),
+    "pcrh_ply_load": (C.c_int, [C.c_char_p, C.c_int, C.c_uint32, _dp, _dp, _up]),
+    "pcrh_ply_save": (C.c_int, [C.c_char_p, _dp, _dp, C.c_uint32]),
+    "pcrh_register_sequence": (C.c_int, [C.POINTER(_dp), _up, C.c_uint32, _dp, _dp, _dp, _up, C.c_char_p, C.c_uint32]),
     "pcrh_conv_reset": (None, [C.c_double]),
     "pcrh_conv_step": (C.c_int, [_dp, _dp, C.c_uint32, _dp, _dp, C.c_uint32, C.POINTER(C.c_int), _dp, C.c_char_p, C.c_uint32]),
 }
@@ -140,6 +143,45 @@ def search(points, queries, k, nearest_first=False, multi_threaded=False, dim=3)
     out = np.empty((len(q), k), np.uint32)
     rc = lib().pcrh_search(_d(p), len(p), dim, _d(q), len(q), k, int(nearest_first), int(multi_threaded), _u(out))
     return out if rc == 0 else None
+
+
+def ply_load(path, with_normals=True):
+    """(xyz, normals or None) of an ASCII PLY in the reference's grammar; None if unreadable."""
+    n = C.c_uint32(0)
+    rc = lib().pcrh_ply_load(path.encode(), int(with_normals), 0, None, None, C.byref(n))
+    if rc == -1:
+        return None
+    xyz = np.empty((n.value, 3))
+    nrm = np.empty((n.value, 3)) if with_normals else None
+    rc = lib().pcrh_ply_load(path.encode(), int(with_normals), n.value, _d(xyz), _d(nrm), C.byref(n))
+    return (xyz, nrm) if rc == 0 else None
+
+
+def ply_save(path, xyz, normals=None):
+    xyz, normals = _pts(xyz), _pts(normals)
+    return lib().pcrh_ply_save(path.encode(), _d(xyz), _d(normals), len(xyz)) == 0
+
+
+def register_sequence(scans, init=None):
+    """Sequential pairwise registration (scan i+1 -> scan i) through CRegistartion.  scans: list of (n_i,3) arrays;
+    init: optional list of (R9, T3).  Returns dict(relative=[(R,T)], absolute=[(R,T)], iterations, msgs)."""
+    scans = [_pts(s) for s in scans]
+    k = len(scans)
+    ptrs = (_dp * k)(*[_d(s) for s in scans])
+    counts = np.array([len(s) for s in scans], np.uint32)
+    ini = None
+    if init is not None:
+        ini = np.concatenate([np.concatenate([np.asarray(R, np.float64).reshape(9), np.asarray(T, np.float64).reshape(3)])
+                              for R, T in init])
+    rel, ab = np.zeros((k - 1, 12)), np.zeros((k - 1, 12))
+    its = np.zeros(k - 1, np.uint32)
+    msgs = C.create_string_buffer(64 * (k - 1))
+    rc = lib().pcrh_register_sequence(ptrs, _u(counts), k, _d(ini), _d(rel), _d(ab), _u(its), msgs, 64)
+    if rc != 0:
+        raise RuntimeError(f"pcrh_register_sequence failed ({rc})")
+    m = [msgs.raw[i * 64:(i + 1) * 64].split(b"\0")[0].decode() for i in range(k - 1)]
+    return dict(relative=[(r[:9].copy(), r[9:].copy()) for r in rel], absolute=[(r[:9].copy(), r[9:].copy()) for r in ab],
+                iterations=its, msgs=m)
 
 
 def conv_reset(unique_sq_dist):

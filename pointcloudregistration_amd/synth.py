@@ -119,6 +119,37 @@ def lidar_pair(n, seed, outlier_frac=0.3, rot_deg=(0.4, -0.3, 1.5), trans=(0.35,
     return np.ascontiguousarray(src), tgt, Rm, t
 
 
+def bumpy_surface(n, seed):
+    """Area-ish-uniform samples of a closed bumpy surface r(u) = 1 + bumps(u): the stand-in for a statue scan."""
+    rng = np.random.default_rng(seed)
+    u = rng.standard_normal((n, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    r = 1.0 + 0.12 * np.sin(3.0 * u[:, 0]) * np.cos(2.0 * u[:, 1]) + 0.08 * np.sin(5.0 * u[:, 2] + 1.0) + 0.05 * np.cos(7.0 * u[:, 0] * u[:, 1])
+    return u * r[:, None]
+
+
+def scan_sequence(num_scans, n, seed, step_deg=2.0, crop_deg=100.0, noise=0.0005):
+    """C2/C4 stand-in: `num_scans` partial views of one bumpy object.  Scan i sees the part of the
+    surface within crop_deg of its viewing direction (which turns by 24 degrees per scan, so neighbours overlap
+    partially), is sampled independently, and is expressed in its own frame, which differs from the previous
+    scan's by a small known motion.  Returns (scans, poses) with x_world = R_i x_scan + t_i."""
+    scans, poses = [], []
+    Rw, tw = np.eye(3), np.zeros(3)
+    for i in range(num_scans):
+        if i:
+            dR = euler_zyx(step_deg * np.cos(i), step_deg * np.sin(1.3 * i), step_deg * 0.7)
+            Rw, tw = Rw @ dR, tw + Rw @ np.array([0.01 * np.cos(i), 0.008 * np.sin(i), 0.004])
+        w = bumpy_surface(int(n * 360.0 / crop_deg / 2.0), seed + i)
+        view = np.array([np.cos(np.deg2rad(24.0 * i)), np.sin(np.deg2rad(24.0 * i)), 0.2])
+        view /= np.linalg.norm(view)
+        cosang = (w / np.linalg.norm(w, axis=1, keepdims=True)) @ view
+        w = w[cosang > np.cos(np.deg2rad(crop_deg))][:n]
+        w = w + np.random.default_rng(seed + 100 + i).standard_normal(w.shape) * noise
+        scans.append(np.ascontiguousarray((w - tw) @ Rw))   # x_scan = R^T (x_world - t)
+        poses.append((Rw.copy(), tw.copy()))
+    return scans, poses
+
+
 def coarse_initial_transform(R_true, t_true, n, rot_spacings=1.5, trans_spacings=1.0):
     """(R0 col-major 9, T0): the known transform composed with a small rigid perturbation, sized in units of
     the cloud's mean point spacing.  ICRP is a FINE registration: its gates are a few spacings wide

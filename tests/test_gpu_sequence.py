@@ -1,0 +1,87 @@
+"""GPU: the callers of the loop (BASELINE configs C2/C4).  A sequence of partial scans of one
+object is registered pairwise through the CRegistartion facade -- every pair checked against the oracle's fit and
+against the known motion -- and the same small problems are run as a batch of concurrent device-resident fits
+(one context = one stream per problem: "replicas only", no collective), which must reproduce the sequential
+results bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REGCFG = ("BaseConvergenceCriteria.MI = 30\nDefaultConvergenceCriteria.AMSE = 0.01\nDefaultConvergenceCriteria.RMSE = 0.01\n"
+          "DefaultConvergenceCriteria.RT = 0.000001\nDefaultConvergenceCriteria.TT = 0.0000001\n"
+          "CorrespondenceEstimationClosestPoints.NN = 4\nCorrespondenceEstimationClosestPoints.SDFT = 36.0\n"
+          "CorrespondenceEstimationClosestPoints.NDFT = 4.0\n")
+STATES = ["NotConverged", "Criteria_Iterations", "Criteria_Transform", "Criteria_AbsMSE", "Criteria_RelMSE",
+          "Criteria_NoCorrespondeces"]
+
+
+@pytest.fixture(scope="module")
+def sequence():
+    from pointcloudregistration_amd import synth
+    return synth.scan_sequence(6, 40000, 4242)
+
+
+def test_register_sequence_matches_oracle_and_truth(sequence, oracle):
+    from pointcloudregistration_amd import hostapi, synth
+    scans, poses = sequence
+    hostapi.reset()
+    hostapi.config_text(REGCFG)
+    out = hostapi.register_sequence(scans)
+    hostapi.reset()
+    Rabs, tabs = np.eye(3), np.zeros(3)
+    for i in range(len(scans) - 1):
+        R, T = out["relative"][i]
+        # parity: the oracle's restatement of CIterativeFit::fit on the same pair
+        want = oracle.fit(scans[i + 1], scans[i], k=4, sdft=36.0, ndft=4.0, conv=oracle.ConvParams.regcfg(30))
+        assert out["iterations"][i] == want["iterations"], i
+        assert out["msgs"][i] == STATES[want["state"]]
+        np.testing.assert_allclose(R, want["R"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(T, want["T"], rtol=0, atol=1e-9)
+        # truth: x_i = R_i^T (R_{i+1} x_{i+1} + t_{i+1} - t_i)
+        (Ri, ti), (Rj, tj) = poses[i], poses[i + 1]
+        Rrel, Trel = Ri.T @ Rj, Ri.T @ (tj - ti)
+        # (the reference's criteria stop as soon as the MSE changes by less than 1 % of the unit distance, well before
+        #  the last bit of the motion is recovered: the fit must have moved towards the truth, not reached it)
+        before = np.abs(np.eye(3) - Rrel).max() + np.abs(Trel).max()
+        after = np.abs(synth.rowcol(R) - Rrel).max() + np.abs(T - Trel).max()
+        assert after < before, (i, before, after)
+        # accumulated pose in the frame of scan 0
+        Rabs, tabs = Rabs @ synth.rowcol(R), Rabs @ T + tabs
+        Ra, Ta = out["absolute"][i]
+        np.testing.assert_allclose(synth.rowcol(Ra), Rabs, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(Ta, tabs, rtol=0, atol=1e-12)
+
+
+def test_batched_concurrent_fits_equal_sequential(sequence, pcr):
+    """C4's 'batched launch path': every pair gets its own context (stream) and device-resident loop; all loops are
+    enqueued interleaved, nothing is read until the end."""
+    scans, _ = sequence
+    pairs = [(scans[i + 1], scans[i]) for i in range(len(scans) - 1)]
+    conv = pcr.ConvergenceParams.regcfg(30)
+
+    def make(ctx, src, tgt):
+        six, tix = pcr.Index(ctx, pcr.Cloud(ctx, src)), pcr.Index(ctx, pcr.Cloud(ctx, tgt))
+        U = tix.unique_sq_dist()
+        return pcr.Fit(ctx, six, tix, 4, U * 36.0, U * 4.0, conv=conv, unique_sq_dist=U, traj_cap=32)
+
+    eye, zero = np.eye(3).reshape(9), np.zeros(3)
+    seq = []
+    ctx0 = pcr.Context(0)
+    for s, t in pairs:
+        seq.append(make(ctx0, s, t).run(eye, zero, 30))
+    ctx0.close()
+    ctxs = [pcr.Context(0) for _ in pairs]
+    fits = [make(c, s, t) for c, (s, t) in zip(ctxs, pairs)]
+    for f in fits:
+        f.reset(eye, zero)
+    for _ in range(30):
+        for f in fits:   # round-robin over the problems: their kernels overlap on the GPU
+            f.step()
+            f.solve()
+    for f, want in zip(fits, seq):
+        got = f.read()
+        assert got["iterations"] == want["iterations"] and got["state"] == want["state"]
+        assert (got["traj"] == want["traj"]).all() and (got["R"] == want["R"]).all() and (got["T"] == want["T"]).all()
+    for c in ctxs:
+        c.close()

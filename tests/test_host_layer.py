@@ -136,3 +136,41 @@ def test_convergence_criteria_matches_oracle(host, oracle, mist, fami):
             assert got[3] == names[want[1]]
             if want[0]:
                 break
+
+
+def test_ply_round_trip_and_reference_grammar(host, tmp_path):
+    """ASCII PLY as the reference reads/writes it (PLYLoad.cpp:76-111, TestUnitity.cpp:278-339): exact round trip,
+    faces and comments ignored, `<id>Norm.ply` layout with 3 extra properties per vertex."""
+    rng = np.random.default_rng(4)
+    xyz, nrm = rng.standard_normal((257, 3)), rng.standard_normal((257, 3))
+    f = str(tmp_path / "scanNorm.ply")
+    assert host.ply_save(f, xyz, nrm)
+    got = host.ply_load(f)
+    assert got is not None and (got[0] == xyz).all() and (got[1] == nrm).all()
+    head = open(f).read().split("end_header")[0]
+    assert head.startswith("ply\nformat ascii 1.0\ncomment VCGLIB generated\nelement vertex 257\n") and "property float nz" in head
+    # positions only
+    g = str(tmp_path / "pos.ply")
+    assert host.ply_save(g, xyz)
+    assert (host.ply_load(g, with_normals=False)[0] == xyz).all()
+    # a file in the layout the reference ships (faces after the vertices)
+    h = tmp_path / "facesNorm.ply"
+    h.write_text("ply\nformat ascii 1.0\ncomment VCGLIB generated\nelement vertex 2\nproperty float x\nproperty float y\n"
+                 "property float z\nproperty float nx\nproperty float ny\nproperty float nz\nelement face 1\n"
+                 "property list uchar int vertex_indices\nend_header\n-0.0655162 0.0774791 0.0596611 0.36987 -0.807545 2.11765 \n"
+                 "1 2 3 0 0 1\n3 0 1 1\n")
+    p, n = host.ply_load(str(h))
+    assert p.tolist() == [[-0.0655162, 0.0774791, 0.0596611], [1.0, 2.0, 3.0]] and n[1].tolist() == [0.0, 0.0, 1.0]
+    assert host.ply_load(str(tmp_path / "missing.ply")) is None
+
+
+def test_reference_scan_patches_load_as_the_golden_inputs(host):
+    """The two scan patches the reference ships (MyLog/2015.1.17/cur_test_data) are the inputs of the patch_*
+    golden cases: reading the PLY files through this loader must give exactly those coordinates."""
+    base = "/root/reference/PointCloudRegistration/MyLog/2015.1.17/cur_test_data"
+    if not os.path.exists(os.path.join(base, "src.ply")):
+        pytest.skip("reference tree not present (GPU box)")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "patch_k4.npz"))
+    for name in ("src", "tgt"):
+        xyz, _ = host.ply_load(os.path.join(base, name + ".ply"))
+        assert xyz.shape == g[name].shape and (xyz == g[name]).all()
