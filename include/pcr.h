@@ -140,6 +140,17 @@ int pcr_knn_d(pcr_ctx *ctx, const pcr_index *index, const double *q_d, uint32_t 
  * throw-away tree. */
 int pcr_unique_sq_dist(pcr_ctx *ctx, const pcr_index *index, double *out);
 
+/* ---- samplers: the step before the loop ---------------------------------------------------------
+ * pcr_sample_random  CSamplerRandom::_doSampleV (Sampler/SamplerRandom.cpp:25-51): point i is kept iff u_i < ratio,
+ *                    u_i a counter-based hash of (seed, i) where the reference calls an unseeded rand().
+ * pcr_sample_grid    one point per occupied cell of the index's grid (the sampler the reference only stubs,
+ *                    Sampler/SamplerUniformGrid.cpp:25-28).
+ * out_idx (host, `cap` slots) receives ascending source indices, *out_count their number; PCR_E_INVALID if they
+ * do not fit. */
+int pcr_sample_random(pcr_ctx *ctx, uint32_t n, double ratio, uint64_t seed, uint32_t cap, uint32_t *out_idx,
+                      uint32_t *out_count);
+int pcr_sample_grid(pcr_ctx *ctx, const pcr_index *index, uint32_t cap, uint32_t *out_idx, uint32_t *out_count);
+
 /* ---- one ICRP iteration ------------------------------------------------------------
  * Replaces, fused into device work:
  *   CCorrespondenceEstimationClosestPoints::_determineCorrespondencesV

@@ -67,6 +67,8 @@ SYMBOLS = {
     "pcr_knn": (C.c_int, [_vp, _vp, _dp, C.c_uint32, C.c_uint32, C.c_int, C.c_double, _up, _dp]),
     "pcr_knn_d": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_int, C.c_double, _vp, _vp]),
     "pcr_unique_sq_dist": (C.c_int, [_vp, _vp, _dp]),
+    "pcr_sample_random": (C.c_int, [_vp, C.c_uint32, C.c_double, C.c_uint64, C.c_uint32, _up, _up]),
+    "pcr_sample_grid": (C.c_int, [_vp, _vp, C.c_uint32, _up, _up]),
     "pcr_icp_step": (C.c_int, [_vp, _vp, _vp, _up, C.c_uint32, _dp, _dp, C.c_uint32, C.c_double, C.c_double,
                                C.c_uint32, _dp, _up, _up, _bp]),
     "pcr_icp_step_d": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _dp, _dp, C.c_uint32, C.c_double,
@@ -299,6 +301,20 @@ def icp_pivots(src_index, tgt_index, R, T):
     pp, pq = np.empty(3), np.empty(3)
     _check(lib().pcr_icp_pivots(src_index.h, tgt_index.h, _d(R), _d(T), _d(pp), _d(pq)), "pcr_icp_pivots")
     return pp, pq
+
+
+def sample_random(ctx, n, ratio, seed=0):
+    out = np.empty(max(n, 1), np.uint32)
+    cnt = C.c_uint32(0)
+    _check(lib().pcr_sample_random(ctx.h, n, ratio, seed, n, _u(out), C.byref(cnt)), "pcr_sample_random")
+    return out[:cnt.value].copy()
+
+
+def sample_grid(ctx, index):
+    out = np.empty(max(index.n, 1), np.uint32)
+    cnt = C.c_uint32(0)
+    _check(lib().pcr_sample_grid(ctx.h, index.h, index.n, _u(out), C.byref(cnt)), "pcr_sample_grid")
+    return out[:cnt.value].copy()
 
 
 class ConvergenceParams(C.Structure):

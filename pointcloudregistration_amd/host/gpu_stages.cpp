@@ -11,6 +11,8 @@ static hiveCommon::CProductFactory<CControlParameters> s_ConfigCreator(CControlP
 static hiveCommon::CProductFactory<CUniqueData> s_SrcUniqueCreator(CUniqueData::getSigSrcUniqueData());
 static hiveCommon::CProductFactory<CUniqueData> s_TgtUniqueCreator(CUniqueData::getSigTgtUniqueData());
 static hiveCommon::CProductFactory<CSamplerIndexList> s_SamplerCreator(CSamplerIndexList::getClassSig());
+static hiveCommon::CProductFactory<CSamplerRandomGPU> s_RandomSamplerCreator(CSamplerRandomGPU::getClassSig());
+static hiveCommon::CProductFactory<CSamplerUniformGridGPU> s_GridSamplerCreator(CSamplerUniformGridGPU::getClassSig());
 static hiveCommon::CProductFactory<CCorrespondenceEstimationClosestPointsGPU> s_EstimationCreator(
     CCorrespondenceEstimationClosestPointsGPU::getClassSig());
 static hiveCommon::CProductFactory<CCorrespondenceRejectionClosestPoints> s_PassThroughCreator(
@@ -70,6 +72,52 @@ CorrespondencePointSet CSamplerIndexList::_doSampleV(const hivePointCloud::CPoin
         Indices.resize(vPointCloud.getNumPoints());
         for (unsigned int i = 0; i < Indices.size(); ++i) Indices[i] = i;
     }
+    return makeSharedPtr<CBasePointCloudSubset>(new CIndexSubset(vPointCloud, Indices));
+}
+
+CorrespondencePointSet CSamplerRandomGPU::_doSampleV(const hivePointCloud::CPointCloud &vPointCloud) {
+    int SampleNum = -1;
+    double SampleRatio = -1.0;
+    unsigned long long Seed = 0;
+    PTR_CONTROL_PARAMS->dumpValue(getKeySampleNum(), SampleNum);
+    PTR_CONTROL_PARAMS->dumpValue(getKeySampleRatio(), SampleRatio);
+    PTR_CONTROL_PARAMS->dumpValue(getKeySeed(), Seed);
+    const int NumPnt = (int)vPointCloud.getNumPoints();
+    double Ratio;
+    if (SampleRatio > 0.0 && SampleRatio < 1.0) Ratio = SampleRatio;  // SamplerRandom.cpp:31-42
+    else if (SampleNum > 0 && SampleNum < NumPnt) Ratio = 1.0 * SampleNum / NumPnt;
+    else return CorrespondencePointSet();  // the reference returns a null subset here
+    CDeviceSession *pSession = CDeviceSession::getInstance();
+    if (!pSession->context()) {
+        hiveEventLogger::hiveOutputWarning(__EXCEPTION_SITE__, "no device context: " + pSession->lastError());
+        return CorrespondencePointSet();
+    }
+    std::vector<unsigned int> Indices(NumPnt);
+    uint32_t Count = 0;
+    const int Status = pcr_sample_random(pSession->context(), (uint32_t)NumPnt, Ratio, Seed, (uint32_t)NumPnt, Indices.data(), &Count);
+    if (Status != PCR_OK) {
+        warn(__EXCEPTION_SITE__, "pcr_sample_random", Status);
+        return CorrespondencePointSet();
+    }
+    Indices.resize(Count);
+    return makeSharedPtr<CBasePointCloudSubset>(new CIndexSubset(vPointCloud, Indices));
+}
+
+CorrespondencePointSet CSamplerUniformGridGPU::_doSampleV(const hivePointCloud::CPointCloud &vPointCloud) {
+    CDeviceSession *pSession = CDeviceSession::getInstance();
+    const SDeviceCloud *pCloud = pSession->acquire(&vPointCloud);
+    if (!pCloud) {
+        hiveEventLogger::hiveOutputWarning(__EXCEPTION_SITE__, "no device index: " + pSession->lastError());
+        return CorrespondencePointSet();
+    }
+    std::vector<unsigned int> Indices(pCloud->NumPoints);
+    uint32_t Count = 0;
+    const int Status = pcr_sample_grid(pSession->context(), pCloud->pIndex, pCloud->NumPoints, Indices.data(), &Count);
+    if (Status != PCR_OK) {
+        warn(__EXCEPTION_SITE__, "pcr_sample_grid", Status);
+        return CorrespondencePointSet();
+    }
+    Indices.resize(Count);
     return makeSharedPtr<CBasePointCloudSubset>(new CIndexSubset(vPointCloud, Indices));
 }
 

@@ -84,6 +84,34 @@ private:
     std::vector<unsigned int> m_IndexList;
 };
 
+// CSamplerRandom (Sampler/SamplerRandom.h:9-33, .cpp:25-58) on the device: same keys, same selection rule
+// (ratio = SR if in (0,1), else SN/N if 0 < SN < N, else no sample set), a seeded counter-based draw where the
+// reference calls an unseeded rand().  SamplerRandom.Seed (no reference counterpart) picks the stream.
+class CSamplerRandomGPU : public CBaseSampler {
+    PCR_FACTORY_CREATABLE(CSamplerRandomGPU)
+public:
+    CSamplerRandomGPU() { _letFactoryReleaseProduct(); }
+    static std::string getClassSig() { return toUpperCopy("SamplerRandomGPU"); }
+    static std::string getKeySampleNum() { return toUpperCopy("SamplerRandom.SN"); }
+    static std::string getKeySampleRatio() { return toUpperCopy("SamplerRandom.SR"); }
+    static std::string getKeySeed() { return toUpperCopy("SamplerRandom.Seed"); }
+
+protected:
+    virtual CorrespondencePointSet _doSampleV(const hivePointCloud::CPointCloud &vPointCloud);
+};
+
+// One point per occupied cell of the cloud's GPU grid: the sampler the reference declares and leaves empty
+// (Sampler/SamplerUniformGrid.cpp:25-28).
+class CSamplerUniformGridGPU : public CBaseSampler {
+    PCR_FACTORY_CREATABLE(CSamplerUniformGridGPU)
+public:
+    CSamplerUniformGridGPU() { _letFactoryReleaseProduct(); }
+    static std::string getClassSig() { return toUpperCopy("SamplerUniformGridGPU"); }
+
+protected:
+    virtual CorrespondencePointSet _doSampleV(const hivePointCloud::CPointCloud &vPointCloud);
+};
+
 class CCorrespondenceEstimationClosestPointsGPU : public CBaseCorrespondenceEstimation {
     PCR_FACTORY_CREATABLE(CCorrespondenceEstimationClosestPointsGPU)
 public:

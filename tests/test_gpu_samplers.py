@@ -1,0 +1,69 @@
+"""GPU: the samplers in front of the loop.  The reference's CSamplerRandom draws from an unseeded
+rand() -- there is no stream to reproduce, so its parity is distributional ("parity unpinned" by construction):
+selection rule, expected count, ascending order, determinism per seed.  The uniform-grid sampler (a stub in the
+reference) is checked against a numpy recomputation of the grid: exactly one sample per occupied cell."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_random_sampler_distribution_and_determinism(pcr, ctx):
+    n = 1_000_000
+    for ratio in (0.01, 0.25, 0.9):
+        a = pcr.sample_random(ctx, n, ratio, seed=7)
+        assert (np.diff(a.astype(np.int64)) > 0).all() and a.max() < n          # ascending, unique, in range
+        sigma = np.sqrt(n * ratio * (1 - ratio))
+        assert abs(len(a) - n * ratio) < 5 * sigma
+        assert (pcr.sample_random(ctx, n, ratio, seed=7) == a).all()            # a pure function of the seed
+        b = pcr.sample_random(ctx, n, ratio, seed=8)
+        assert len(np.intersect1d(a, b)) < 1.2 * n * ratio * ratio + 5 * sigma  # independent streams
+        # uniform over the index range: chi-square on 64 bins
+        h = np.histogram(a, bins=64, range=(0, n))[0]
+        e = len(a) / 64
+        assert ((h - e) ** 2 / e).sum() < 130
+    assert len(pcr.sample_random(ctx, n, 0.0)) == 0 and len(pcr.sample_random(ctx, 1000, 1.0)) == 1000
+    assert len(pcr.sample_random(ctx, 0, 0.5)) == 0
+    with pytest.raises(pcr.PcrError):
+        pcr.sample_random(ctx, 10, 1.5)
+
+
+def test_grid_sampler_one_point_per_occupied_cell(pcr, ctx):
+    from pointcloudregistration_amd import synth
+    src, _, _, _ = synth.registration_pair(200000, 1000, 3)
+    ix = pcr.Index(ctx, pcr.Cloud(ctx, src), kind=pcr.INDEX_GRID)
+    smp = pcr.sample_grid(ctx, ix)
+    info = ix.info()
+    assert len(smp) == info["occupied_cells"]
+    assert (np.diff(smp.astype(np.int64)) > 0).all()
+    # every sample sits in a cell of its own, and every point's cell has a sample
+    lo, h, g = src.min(0), info["cell_size"], np.array(info["dims"])
+    cell = np.minimum(np.maximum(((src - lo) / h).astype(np.int64), 0), g - 1)
+    cid = (cell[:, 2] * g[1] + cell[:, 1]) * g[0] + cell[:, 0]
+    assert len(np.unique(cid[smp])) == len(smp)
+    assert len(np.setdiff1d(np.unique(cid), cid[smp])) <= 2   # (a point on a cell face may round the other way in numpy)
+
+
+def test_samplers_behind_the_plugin_interface():
+    from pointcloudregistration_amd import hostapi, synth
+    src, tgt, Rm, t = synth.registration_pair(30000, 30000, 9)
+    R0, T0 = synth.coarse_initial_transform(Rm, t, 30000)
+    hostapi.reset()
+    base = ("BaseConvergenceCriteria.MI = 30\nDefaultConvergenceCriteria.RT = 0.000001\nDefaultConvergenceCriteria.TT = 0.0000001\n"
+            "CorrespondenceEstimationClosestPoints.SDFT = 36.0\nCorrespondenceEstimationClosestPoints.NDFT = 4.0\n")
+    hostapi.config_text(base + "SamplerRandom.SR = 0.2\nSamplerRandom.Seed = 5\n")
+    a = hostapi.fit(src, tgt, R0=R0, T0=T0, sampler="SamplerRandomGPU")
+    hostapi.reset()
+    hostapi.config_text(base + "SamplerRandom.SR = 0.2\nSamplerRandom.Seed = 5\n")
+    b = hostapi.fit(src, tgt, R0=R0, T0=T0, sampler="SamplerRandomGPU")
+    assert a["status"] == 0 and a["iterations"] >= 2 and (a["R"] == b["R"]).all()      # seeded: repeatable
+    assert abs(a["traj"][0, 13] / 30000 - 0.2 * 0.6) < 0.05                          # ~20 % sampled, ~60 % of those kept
+    hostapi.reset()
+    hostapi.config_text(base)
+    c = hostapi.fit(src, tgt, R0=R0, T0=T0, sampler="SamplerUniformGridGPU")
+    assert c["status"] == 0 and c["iterations"] >= 2 and 1000 < c["traj"][0, 13] < 30000
+    hostapi.reset()
+    hostapi.config_text(base)   # neither SR nor SN: the reference returns a null sample set -> "Point Cloud Not Valid!"
+    d = hostapi.fit(src, tgt, R0=R0, T0=T0, sampler="SamplerRandomGPU")
+    assert d["iterations"] == 0 and d["msg"] == "Point Cloud Not Valid!"
+    hostapi.reset()
