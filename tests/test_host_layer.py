@@ -49,6 +49,7 @@ def test_host_library_exports_every_declared_symbol(host):
 def test_plugins_registered_under_reference_style_signatures(host):
     for sig in ["CorrespondenceEstimationClosestPointsGPU", "CorrespondenceRejectionClosestPoints", "RejectionCentroidDistGPU",
                 "TransformationEstimationSVD2GPU", "DefaultConvergenceCriteria", "BaseConvergenceCriteria", "SamplerIndexList",
+                "SamplerRandomGPU", "SamplerUniformGridGPU",
                 "SrcUniqueData", "TgtUniqueData", "RegistrationConfig"]:
         assert host.is_registered(sig), sig
         assert host.is_registered(sig.upper())
