@@ -106,6 +106,8 @@ typedef struct {
     double cell_size;         /* > 0 fixes the cell edge and skips the occupancy search   */
     uint64_t max_cells;       /* cap on grid cells (dense cell table); 0: 2^30            */
     uint32_t brute_max_points;/* AUTO threshold; 0: 2048                                  */
+    uint32_t max_levels;      /* nested grids for clouds of very uneven density (a dense
+                               * region gets a finer grid of its own); 0: 6, 1: one grid  */
 } pcr_index_params;
 typedef struct {
     int kind;
@@ -113,6 +115,8 @@ typedef struct {
     uint64_t cells, occupied_cells;
     double cell_size, mean_occupancy;
     uint32_t max_occupancy;
+    uint32_t levels;          /* grids in the index; dims and cell_size describe level 0,
+                               * cells / occupied_cells / max_occupancy all levels        */
     uint64_t device_bytes;
 } pcr_index_info;
 int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params *params /*nullable*/,

@@ -35,13 +35,13 @@ class PcrError(RuntimeError):
 
 class IndexParams(C.Structure):
     _fields_ = [("kind", C.c_int), ("target_occupancy", C.c_double), ("cell_size", C.c_double),
-                ("max_cells", C.c_uint64), ("brute_max_points", C.c_uint32)]
+                ("max_cells", C.c_uint64), ("brute_max_points", C.c_uint32), ("max_levels", C.c_uint32)]
 
 
 class IndexInfo(C.Structure):
     _fields_ = [("kind", C.c_int), ("n", C.c_uint32), ("dims", C.c_uint32 * 3), ("cells", C.c_uint64),
                 ("occupied_cells", C.c_uint64), ("cell_size", C.c_double), ("mean_occupancy", C.c_double),
-                ("max_occupancy", C.c_uint32), ("device_bytes", C.c_uint64)]
+                ("max_occupancy", C.c_uint32), ("levels", C.c_uint32), ("device_bytes", C.c_uint64)]
 
 
 # every symbol include/pcr.h declares: (restype, argtypes)
@@ -219,11 +219,11 @@ class Index:
     """pcr_index over a Cloud."""
 
     def __init__(self, ctx, cloud, kind=INDEX_AUTO, target_occupancy=0.0, cell_size=0.0, max_cells=0,
-                 brute_max_points=0):
+                 brute_max_points=0, max_levels=0):
         self.ctx, self.cloud = ctx, cloud
         self.h = _vp()
         ctx._children.add(self)
-        prm = IndexParams(kind, target_occupancy, cell_size, max_cells, brute_max_points)
+        prm = IndexParams(kind, target_occupancy, cell_size, max_cells, brute_max_points, max_levels)
         _check(lib().pcr_index_build(ctx.h, cloud.h, C.byref(prm), C.byref(self.h)), "pcr_index_build")
         self.n = cloud.n
 

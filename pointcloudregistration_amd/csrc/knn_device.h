@@ -125,6 +125,19 @@ __device__ __forceinline__ int cell_coord(double v, double lo, double inv_h, int
     return (int)t;
 }
 
+// Distance from coordinate s to the slab of cells with index c along one axis (0 inside), shrunk by the margin.
+__device__ __forceinline__ double slab_gap(double s, double lo, int c, double h, double margin) {
+    const double f0 = lo + (double)c * h, f1 = lo + (double)(c + 1) * h;
+    const double gap = fmax(fmax(f0 - s, s - f1), 0.0) - margin;
+    return gap > 0.0 ? gap : 0.0;
+}
+
+// sqrt(v) for v >= 0 (or +inf), never too small: a float root, inflated past its rounding.  Only ever used to
+// decide which cells to open, with a cell of slack on top.
+__device__ __forceinline__ double ball_half_width(double v) {
+    return (double)sqrtf(__double2float_ru(v)) * 1.000001;
+}
+
 // Squared lower bound on the distance from the grid-frame query s to every point whose cell lies
 // OUTSIDE the cell box [x0..x1]x[y0..y1]x[z0..z1] (faces on the grid boundary have nothing beyond
 // them).  Conservative against rounding: each face gap is shrunk by `margin`; o?2 are the squared
@@ -262,60 +275,85 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
         pz1 = min(cz + (r_start - 1), gz - 1);
     }
     const int rmax = max(max(gx, gy), gz);
-    // Shell radius: not one ring at a time.  Once K candidates are known, everything that can still matter lies
-    // within sqrt(wd) of the query, so the NEXT shell is made thick enough to cover that at once; while fewer than
-    // K are known the radius doubles.  A query far from the data (an outlier in empty space) thus costs one or a
-    // few box scans instead of hundreds of shells whose inner rows are re-opened every time.
+    const double inv_bs = 1.0 / bound_scale;
+    DIAG_LANE_ADD(8 * (KC == 1) + 6, 1);  // shell searches
     for (int r = r_start; r <= rmax;) {
+        DIAG_LANE_ADD(8 * (KC == 1) + 7, 1);  // shells
         const int x0 = max(cx - r, 0), x1 = min(cx + r, gx - 1);
         const int y0 = max(cy - r, 0), y1 = min(cy + r, gy - 1);
         const int z0 = max(cz - r, 0), z1 = min(cz + r, gz - 1);
-        const int ny = y1 - y0 + 1;
-        const int nrows = ny * (z1 - z0 + 1);
-        // ---- flattened scan of the shell: one candidate per trip, rows advanced on demand ----
-        int row = 0, ry = y0, rz = z0, seg = 0;
+        // ---- flattened scan of the shell: one candidate per trip, rows advanced on demand.  Of the box only the
+        // part inside the BALL of everything that can still matter is enumerated: a layer's rows are limited to
+        // the disc the ball cuts out of it, a row's cells to the chord (one cell of slack either side; the radius
+        // is a float square root rounded up).  A query hovering above a dense surface thus opens the few rows below
+        // it, not the whole box. ----
+        int rz = z0 - 1, ry = 0, ylast = -1, seg = 0;
+        double rem_z = 0.0;
         uint32_t p = 0, e = 0;
         for (;;) {
+            bool exhausted = false;
             while (p >= e) {
-                if (row >= nrows) break;
+                if (seg == 0) {  // next row; next layer when the current one has no rows left
+                    ++ry;
+                    while (ry > ylast) {
+                        if (++rz > z1) {
+                            exhausted = true;
+                            break;
+                        }
+                        const double reach = fmin(wd, max_d2) * inv_bs;
+                        const double dz = slab_gap(sz, g.lo[2], rz, g.h, margin);
+                        rem_z = reach - dz * dz;
+                        if (!(rem_z >= 0.0)) continue;  // the whole layer is out of reach
+                        const double w = ball_half_width(rem_z) + margin;
+                        double lo_c = (sy - w - g.lo[1]) * g.inv_h - 1.0, hi_c = (sy + w - g.lo[1]) * g.inv_h + 1.0;
+                        lo_c = fmin(fmax(lo_c, (double)y0), (double)y1 + 1.0);
+                        hi_c = fmax(fmin(hi_c, (double)y1), (double)y0 - 1.0);
+                        ry = (int)lo_c;
+                        ylast = (int)hi_c;
+                    }
+                    if (exhausted) break;
+                }
                 const bool inner = (ry >= py0) & (ry <= py1) & (rz >= pz0) & (rz <= pz1);
                 int xs, xe;
-                bool advance;
                 if (!inner) {
                     xs = x0;
                     xe = x1;
-                    advance = true;
                 } else if (seg == 0) {
                     xs = x0;
                     xe = px0 - 1;
                     seg = 1;
-                    advance = false;
                 } else {
                     xs = px1 + 1;
                     xe = x1;
                     seg = 0;
-                    advance = true;
                 }
                 if (xs <= xe) {
-                    const size_t base = ((size_t)rz * gy + ry) * gx;
-                    p = cs[base + xs];
-                    e = cs[base + xe + 1];
-                    if constexpr (WINDOW) {
-                        if (e - p > PCR_LONG_RANGE && e > p) {  // dense stretch: enter at the query's x instead
-                            windowed_scan<KC>(g.pts, cand, p, e, qx, qy, qz, sx, margin, bound_scale, top, wd, wi);
-                            p = e;
+                    const double dy = slab_gap(sy, g.lo[1], ry, g.h, margin);
+                    const double rem = rem_z - dy * dy;
+                    if (rem >= 0.0) {
+                        const double w = ball_half_width(rem) + margin;
+                        double lo_c = (sx - w - g.lo[0]) * g.inv_h - 1.0, hi_c = (sx + w - g.lo[0]) * g.inv_h + 1.0;
+                        lo_c = fmin(fmax(lo_c, (double)xs), (double)xe + 1.0);
+                        hi_c = fmax(fmin(hi_c, (double)xe), (double)xs - 1.0);
+                        xs = (int)lo_c;
+                        xe = (int)hi_c;
+                        if (xs <= xe) {
+                            DIAG_LANE_ADD(8 * (KC == 1) + 3, 1);  // rows opened by the shell search
+                            const size_t base = ((size_t)rz * gy + ry) * gx;
+                            p = cs[base + xs];
+                            e = cs[base + xe + 1];
+                            if constexpr (WINDOW) {
+                                if (e - p > PCR_LONG_RANGE && e > p) {  // dense stretch: enter at the query's x instead
+                                    windowed_scan<KC>(g.pts, cand, p, e, qx, qy, qz, sx, margin, bound_scale, top, wd, wi);
+                                    p = e;
+                                }
+                            }
                         }
-                    }
-                }
-                if (advance) {
-                    ++row;
-                    if (++ry > y1) {
-                        ry = y0;
-                        ++rz;
                     }
                 }
             }
             if (p >= e) break;
+            DIAG_LANE_ADD(8 * (KC == 1) + 4, 1);  // candidates of the shell search
             const Pt4 c = cand[p];
             const double d = sqdist3(qx, qy, qz, c.x, c.y, c.z);
             const uint32_t ci = (uint32_t)c.w;
@@ -339,14 +377,16 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
         py1 = y1;
         pz0 = z0;
         pz1 = z1;
+        // Next radius: double, but never past what the ball of everything that can still matter needs.  (Doubling
+        // even when the K-th distance is known: it may come from another level of the index, or from a far
+        // candidate, and say little about where THIS grid's points are; the shells scanned on the way cost a
+        // third of the last one.)
         const double reach2 = fmin(wd, max_d2);  // nothing at or beyond this squared distance can matter
-        int rn = r + 1;
+        int rn = 2 * r;
         if (reach2 < PCR_INF) {
-            const double cells_needed = (sqrt(reach2 / bound_scale) + margin) * g.inv_h + 2.0;
+            const double cells_needed = (sqrt(reach2 * inv_bs) + margin) * g.inv_h + 2.0;
             const int need = cells_needed < (double)rmax ? (int)cells_needed : rmax;
-            rn = wd < PCR_INF ? max(rn, need) : max(rn, min(2 * r, need));
-        } else {
-            rn = max(rn, 2 * r);
+            rn = max(r + 1, min(rn, need));
         }
         r = min(rn, rmax);  // at r == rmax the box is the whole grid and the loop ends through `all`
     }
@@ -427,8 +467,8 @@ __device__ __forceinline__ bool ring1_pruned(const GridView &g, const Pt4 *__res
             const double gyz = (double)__uint_as_float(row.x);
             // rows outside the grid carry +inf; the explicit test matters while wd itself is still +inf
             if ((row.x != 0x7f800000u) & !(wd < gyz)) {
-                const uint32_t xs = has_xl & !(wd < gyz + gxl) ? row.y - 1u : row.y;
-                const uint32_t xe = has_xh & !(wd < gyz + gxh) ? row.y + 2u : row.y + 1u;
+                const uint32_t xs = (has_xl & !(wd < gyz + gxl)) ? row.y - 1u : row.y;
+                const uint32_t xe = (has_xh & !(wd < gyz + gxh)) ? row.y + 2u : row.y + 1u;
                 p = cs[xs];
                 e = cs[xe];
                 if (e - p > PCR_LONG_RANGE && e > p) {  // dense stretch: enter at the query's x instead
@@ -483,9 +523,101 @@ __device__ __forceinline__ void lane_search(const GridView &g, const Pt4 *__rest
                                             uint2 *rowtab) {
     DIAG_LANE_ADD(8 * (KC == 1) + 5, 1);  // lane searches
     const bool fin1 = ring1_pruned<KC>(g, cand, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, rowtab);
-    DIAG_LANE_ADD(8 * (KC == 1) + 6, fin1 ? 0 : 1);  // lanes continuing with ring 2
     if (!fin1)
         grid_search<KC, false>(g, cand, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, 2);
+}
+
+// squared distance from the grid-frame query to a level's box of points, shrunk by the margin (0 inside)
+__device__ __forceinline__ double level_box_dist2(const GridView &g, double sx, double sy, double sz, double margin) {
+    double ox = fmax(fmax(g.lo[0] - sx, sx - g.hi[0]), 0.0) - margin;
+    double oy = fmax(fmax(g.lo[1] - sy, sy - g.hi[1]), 0.0) - margin;
+    double oz = fmax(fmax(g.lo[2] - sz, sz - g.hi[2]), 0.0) - margin;
+    ox = ox > 0.0 ? ox : 0.0;
+    oy = oy > 0.0 ? oy : 0.0;
+    oz = oz > 0.0 ? oz : 0.0;
+    return ox * ox + oy * oy + oz * oz;
+}
+
+// Has the 3x3x3 walk around the query's cell settled a level for the K-th distance wd?  The bound of the end of
+// ring1_pruned, from the geometry alone -- asked again later, when other levels have shrunk wd -- and sharper for a
+// query outside the level's box: whatever lies beyond a face of the 3x3x3 box is also at least as far away
+// along the OTHER axes as the box of the points is.
+__device__ __forceinline__ bool ring1_settles(const GridView &g, double sx, double sy, double sz, double margin,
+                                              double bound_scale, double wd, double max_d2) {
+    const double s[3] = {sx, sy, sz};
+    double face2[3][2], o2[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int c = cell_coord(s[a], g.lo[a], g.inv_h, g.g[a]);
+        double gl = s[a] - (g.lo[a] + (double)c * g.h) - margin;
+        double gh = (g.lo[a] + (double)(c + 1) * g.h) - s[a] - margin;
+        gl = gl > 0.0 ? gl : 0.0;
+        gh = gh > 0.0 ? gh : 0.0;
+        face2[a][0] = c > 1 ? (gl + g.h) * (gl + g.h) : PCR_INF;
+        face2[a][1] = c < g.g[a] - 2 ? (gh + g.h) * (gh + g.h) : PCR_INF;
+        double o = fmax(fmax(g.lo[a] - s[a], s[a] - g.hi[a]), 0.0) - margin;
+        o = o > 0.0 ? o : 0.0;
+        o2[a] = o * o;
+    }
+    double b2 = fmin(face2[0][0], face2[0][1]) + (o2[1] + o2[2]);
+    b2 = fmin(b2, fmin(face2[1][0], face2[1][1]) + (o2[0] + o2[2]));
+    b2 = fmin(b2, fmin(face2[2][0], face2[2][1]) + (o2[0] + o2[1]));
+    b2 *= bound_scale * (1.0 - 4.440892098500626e-16);
+    return (wd < b2) | (max_d2 <= b2);
+}
+
+// The search over all levels of an index, in two passes.
+//   1. The 3x3x3 walk on every level that can hold a better point.  A level the query lies outside of is entered
+//      at its cell nearest to the query.  Cheap, and afterwards the K-th distance is finite for all but the
+//      strangest queries.
+//   2. The levels that walk did not settle are completed with the shell search, whose reach is now bounded by what
+//      the OTHER levels found: a query in the hole a finer level left in a coarse one does not wander through the
+//      hole looking for K points of that level.
+// Order in both passes: the levels whose box holds the query, finest first (that is where the nearest points are),
+// then the others from coarse to fine -- the boxes are nested, so that is by increasing distance -- each skipped
+// once its whole box is provably farther than the current K-th best.  One call site per pass (2 x levels slots).
+// Exact: every level is searched exactly against the running top-K, and the levels partition the cloud.
+template <int KC>
+__device__ __forceinline__ void multi_lane_search(const MultiView &M, const Pt4 *__restrict__ cand_all, double qx, double qy,
+                                                  double qz, double sx, double sy, double sz, double max_d2,
+                                                  double bound_scale, double extra_margin, TopK<KC> &top, uint2 *rowtab) {
+    const int L = M.levels;
+    const double qmargin = extra_margin + 9.094947017729282e-13 * (fabs(sx) + fabs(sy) + fabs(sz));
+    uint32_t holds = 0, open = 0;
+    for (int it = 0; it < 2 * L; ++it) {
+        const int l = it < L ? L - 1 - it : it - L;
+        const GridView &g = M.v[l];
+        bool go;
+        if (it < L) {
+            const double pad = 2.0 * g.h;  // a query a couple of cells outside is as good as inside
+            go = (l == 0) | ((sx >= g.lo[0] - pad) & (sx <= g.hi[0] + pad) & (sy >= g.lo[1] - pad) & (sy <= g.hi[1] + pad) &
+                             (sz >= g.lo[2] - pad) & (sz <= g.hi[2] + pad));
+            holds |= go ? 1u << l : 0u;
+        } else {
+            const double b2 = level_box_dist2(g, sx, sy, sz, g.margin + qmargin) * bound_scale;
+            go = !((holds >> l) & 1u) & !((top.worst_d() < b2) | (max_d2 <= b2));
+        }
+        if (go) {
+            DIAG_LANE_ADD(8 * (KC == 1) + 5, 1);  // ring walks
+            const bool settled = ring1_pruned<KC>(g, cand_all + (g.pts - M.all), qx, qy, qz, sx, sy, sz, max_d2, bound_scale,
+                                                  extra_margin, top, rowtab);
+            open |= settled ? 0u : 1u << l;
+        }
+    }
+    if (__any(open != 0))
+        for (int it = 0; it < 2 * L; ++it) {
+            const int l = it < L ? L - 1 - it : it - L;
+            const GridView &g = M.v[l];
+            bool go = ((open >> l) & 1u) & (((holds >> l) & 1u) == (it < L ? 1u : 0u));
+            if (go) {
+                const double b2 = level_box_dist2(g, sx, sy, sz, g.margin + qmargin) * bound_scale;
+                go = !((top.worst_d() < b2) | (max_d2 <= b2)) &&
+                     !ring1_settles(g, sx, sy, sz, g.margin + qmargin, bound_scale, top.worst_d(), max_d2);
+            }
+            if (go)
+                grid_search<KC, true>(g, cand_all + (g.pts - M.all), qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top,
+                                      2);
+        }
 }
 
 // Brute-force scan of one LDS tile (all lanes read the same address: LDS broadcast).

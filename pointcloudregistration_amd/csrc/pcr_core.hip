@@ -23,10 +23,13 @@ void set_last_error(const char *fmt, ...) {
 }
 
 // ------------------------------------------------------------------ bounds
+// lvl (nullable): level of every point; only points of level `want` take part (NULL: all of them)
 __global__ void __launch_bounds__(256) bounds_kernel(const double *__restrict__ xyz, uint32_t n,
+                                                     const uint8_t *__restrict__ lvl, uint8_t want,
                                                      double *__restrict__ out /*[gridDim.x][6]*/) {
     double lo[3] = {PCR_INF_H, PCR_INF_H, PCR_INF_H}, hi[3] = {-PCR_INF_H, -PCR_INF_H, -PCR_INF_H};
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (lvl && lvl[i] != want) continue;
         for (int a = 0; a < 3; ++a) {
             const double v = xyz[(size_t)i * 3 + a];
             lo[a] = fmin(lo[a], v);
@@ -70,8 +73,10 @@ __device__ __forceinline__ uint32_t cell_of(const GridGeom &G, double x, double 
 }
 
 __global__ void __launch_bounds__(256) cell_histogram_kernel(const double *__restrict__ xyz, uint32_t n, GridGeom G,
+                                                             const uint8_t *__restrict__ lvl, uint8_t want,
                                                              uint32_t *__restrict__ counts) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (lvl && lvl[i] != want) continue;
         const uint32_t c = cell_of(G, xyz[(size_t)i * 3], xyz[(size_t)i * 3 + 1], xyz[(size_t)i * 3 + 2]);
         atomicAdd(&counts[c], 1u);
     }
@@ -167,8 +172,10 @@ __global__ void __launch_bounds__(256) scan_apply_kernel(uint32_t *__restrict__ 
 }
 
 __global__ void __launch_bounds__(256) scatter_kernel(const double *__restrict__ xyz, uint32_t n, GridGeom G,
+                                                      const uint8_t *__restrict__ lvl, uint8_t want,
                                                       uint32_t *__restrict__ cursor, Pt4 *__restrict__ pts) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (lvl && lvl[i] != want) continue;
         const double x = xyz[(size_t)i * 3], y = xyz[(size_t)i * 3 + 1], z = xyz[(size_t)i * 3 + 2];
         const uint32_t c = cell_of(G, x, y, z);
         const uint32_t p = atomicAdd(&cursor[c], 1u);
@@ -222,6 +229,73 @@ __global__ void __launch_bounds__(256) pack_kernel(const double *__restrict__ xy
         pts[i] = o;
         pos_of[i] = i;
     }
+}
+
+// ------------------------------------------------------------------ nested levels (uneven density)
+// Where are the cells that hold too many points?  For two thresholds thr[0] <= thr[1], over the cells with more
+// than thr[t] points: their total mass and the box of their cell coordinates.
+//   stats[t*8 + 0] mass, [t*8 + 1..3] min cell coordinate per axis, [t*8 + 4..6] max cell coordinate per axis
+// (initialised by the host to 0 / 0xffffffff / 0).  One atomic set per wave.
+__global__ void __launch_bounds__(256) heavy_stats_kernel(const uint32_t *__restrict__ counts, uint64_t cells, uint32_t gx,
+                                                          uint32_t gy, uint32_t thr0, uint32_t thr1,
+                                                          uint32_t *__restrict__ stats) {
+    uint32_t mass[2] = {0, 0}, mn[2][3], mx[2][3];
+    for (int t = 0; t < 2; ++t)
+        for (int a = 0; a < 3; ++a) {
+            mn[t][a] = 0xffffffffu;
+            mx[t][a] = 0u;
+        }
+    for (uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x; c < cells; c += (uint64_t)gridDim.x * 256) {
+        const uint32_t v = counts[c];
+        if (v > thr0) {
+            const uint32_t co[3] = {(uint32_t)(c % gx), (uint32_t)((c / gx) % gy), (uint32_t)(c / ((uint64_t)gx * gy))};
+            for (int t = 0; t < 2; ++t)
+                if (v > (t ? thr1 : thr0)) {
+                    mass[t] += v;
+                    for (int a = 0; a < 3; ++a) {
+                        mn[t][a] = min(mn[t][a], co[a]);
+                        mx[t][a] = max(mx[t][a], co[a]);
+                    }
+                }
+        }
+    }
+    for (int t = 0; t < 2; ++t) {
+        for (int off = 32; off > 0; off >>= 1) {
+            mass[t] += __shfl_down(mass[t], off, 64);
+            for (int a = 0; a < 3; ++a) {
+                mn[t][a] = min(mn[t][a], (uint32_t)__shfl_down(mn[t][a], off, 64));
+                mx[t][a] = max(mx[t][a], (uint32_t)__shfl_down(mx[t][a], off, 64));
+            }
+        }
+        if ((threadIdx.x & 63) == 0 && mass[t]) {
+            atomicAdd(&stats[t * 8], mass[t]);
+            for (int a = 0; a < 3; ++a) {
+                atomicMin(&stats[t * 8 + 1 + a], mn[t][a]);
+                atomicMax(&stats[t * 8 + 4 + a], mx[t][a]);
+            }
+        }
+    }
+}
+
+struct Box3 {
+    double lo[3], hi[3];
+};
+
+// points of level `want` inside the box move one level down; *moved counts them
+__global__ void __launch_bounds__(256) assign_level_kernel(const double *__restrict__ xyz, uint32_t n, Box3 B,
+                                                           uint8_t *__restrict__ lvl, uint8_t want,
+                                                           uint32_t *__restrict__ moved) {
+    uint32_t c = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (lvl[i] != want) continue;
+        const double x = xyz[(size_t)i * 3], y = xyz[(size_t)i * 3 + 1], z = xyz[(size_t)i * 3 + 2];
+        if ((x >= B.lo[0]) & (x <= B.hi[0]) & (y >= B.lo[1]) & (y <= B.hi[1]) & (z >= B.lo[2]) & (z <= B.hi[2])) {
+            lvl[i] = want + 1;
+            ++c;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(moved, c);
 }
 
 // ------------------------------------------------------------------ brick ordering of queries
@@ -285,10 +359,10 @@ __global__ void __launch_bounds__(256) brick_histogram_kernel(const Pt4 *__restr
 }
 
 __global__ void __launch_bounds__(256) brick_scatter_kernel(const uint32_t *__restrict__ brick_id, uint32_t n,
-                                                            uint32_t *__restrict__ cursor,
+                                                            uint32_t base, uint32_t *__restrict__ cursor,
                                                             uint32_t *__restrict__ order) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        order[atomicAdd(&cursor[brick_id[i]], 1u)] = i;
+        order[atomicAdd(&cursor[brick_id[i]], 1u)] = base + i;
 }
 
 // After the scatter cursor[b] == end of brick b; start = end of the previous brick.  The scatter's atomics
@@ -348,11 +422,12 @@ static int grid_blocks(uint64_t work, int block = 256, int cap = 2048) {
     return (int)b;
 }
 
-static int compute_bounds(pcr_ctx *ctx, const double *xyz_d, uint32_t n, double lo[3], double hi[3]) {
+static int compute_bounds(pcr_ctx *ctx, const double *xyz_d, uint32_t n, const uint8_t *lvl_d, uint8_t want, double lo[3],
+                          double hi[3]) {
     const int nb = grid_blocks(n, 256, 1024);
     double *out_d = nullptr;
     PCR_HIP(hipMalloc(&out_d, sizeof(double) * 6 * nb));
-    hipLaunchKernelGGL(bounds_kernel, dim3(nb), dim3(256), 0, ctx->stream, xyz_d, n, out_d);
+    hipLaunchKernelGGL(bounds_kernel, dim3(nb), dim3(256), 0, ctx->stream, xyz_d, n, lvl_d, want, out_d);
     std::vector<double> h((size_t)6 * nb);
     hipError_t e = hipMemcpyAsync(h.data(), out_d, sizeof(double) * 6 * nb, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -372,7 +447,7 @@ static int compute_bounds(pcr_ctx *ctx, const double *xyz_d, uint32_t n, double 
 
 
 int brick_order(pcr_ctx *ctx, const GridView &g, const Pt4 *pts, const double *xyz_aos, uint32_t n,
-                uint32_t *order_d, bool deterministic) {
+                uint32_t *order_d, bool deterministic, uint32_t base) {
     BrickGeom B;
     for (int a = 0; a < 3; ++a) {
         B.G.lo[a] = g.lo[a];
@@ -404,8 +479,8 @@ int brick_order(pcr_ctx *ctx, const GridView &g, const Pt4 *pts, const double *x
                        stats);
     hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, tile_sums, tiles);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(tiles), dim3(256), 0, ctx->stream, counts, nbricks, tile_sums, n);
-    hipLaunchKernelGGL(brick_scatter_kernel, dim3(grid_blocks(n)), dim3(256), 0, ctx->stream, brick_id, n, counts,
-                       order_d);
+    hipLaunchKernelGGL(brick_scatter_kernel, dim3(grid_blocks(n)), dim3(256), 0, ctx->stream, brick_id, n, base,
+                       counts, order_d);
     if (deterministic)
         hipLaunchKernelGGL(brick_sort_kernel, dim3(2048), dim3(256), 0, ctx->stream, counts, (uint32_t)nbricks,
                            order_d);
@@ -680,7 +755,7 @@ static int cloud_finish(pcr_ctx *ctx, pcr_cloud *c) {
         for (int a = 0; a < 3; ++a) c->lo[a] = c->hi[a] = 0.0;
         return PCR_OK;
     }
-    return compute_bounds(ctx, c->xyz_d, c->n, c->lo, c->hi);
+    return compute_bounds(ctx, c->xyz_d, c->n, nullptr, 0, c->lo, c->hi);
 }
 
 int pcr_cloud_upload(pcr_ctx *ctx, const double *xyz, uint32_t n, pcr_cloud **out) {
@@ -755,40 +830,45 @@ int pcr_index_free(pcr_index *ix) {
     hipSetDevice(ix->ctx->device);
     if (ix->pts_d) hipFree(ix->pts_d);
     if (ix->tpts_d) hipFree(ix->tpts_d);
-    if (ix->cs_d) hipFree(ix->cs_d);
+    for (int l = 0; l < PCR_MAX_LEVELS; ++l)
+        if (ix->cs_d[l]) hipFree(ix->cs_d[l]);
     if (ix->pos_of_d) hipFree(ix->pos_of_d);
     if (ix->order_d) hipFree(ix->order_d);
     delete ix;
     return PCR_OK;
 }
 
-// one trial of the histogram at a given cell size: fills counts (device) and returns statistics
-static int histogram_trial(pcr_ctx *ctx, const pcr_cloud *cloud, const GridGeom &G, uint64_t cells,
-                           uint32_t *counts_d, uint32_t *tile_sums_d, unsigned long long *stats_d,
-                           unsigned long long stats_h[2]) {
-    PCR_HIP(hipMemsetAsync(counts_d, 0, sizeof(uint32_t) * (cells + 1), ctx->stream));
-    PCR_HIP(hipMemsetAsync(stats_d, 0, sizeof(unsigned long long) * 2, ctx->stream));
-    hipLaunchKernelGGL(cell_histogram_kernel, dim3(grid_blocks(cloud->n)), dim3(256), 0, ctx->stream, cloud->xyz_d,
-                       cloud->n, G, counts_d);
-    const uint32_t tiles = (uint32_t)((cells + SCAN_TILE - 1) / SCAN_TILE);
-    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(tiles), dim3(256), 0, ctx->stream, counts_d, cells, tile_sums_d,
-                       stats_d);
-    PCR_HIP(hipMemcpyAsync(stats_h, stats_d, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, ctx->stream));
-    PCR_HIP(hipStreamSynchronize(ctx->stream));
-    return PCR_OK;
+namespace {
+
+// Everything the build of ONE level's grid needs and leaves behind.
+struct LevelBuild {
+    GridGeom G;
+    double h;
+    uint64_t cells;
+    uint32_t *counts_d;     // [cells+1]: histogram, then exclusive starts; becomes the level's cell table
+    uint32_t *tile_sums_d;  // scan scratch
+    size_t counts_cap, tiles_cap;
+    unsigned long long stats_h[2];  // occupied cells, largest cell
+};
+
+void release(LevelBuild &B) {
+    if (B.counts_d) hipFree(B.counts_d);
+    if (B.tile_sums_d) hipFree(B.tile_sums_d);
+    B.counts_d = B.tile_sums_d = nullptr;
+    B.counts_cap = B.tiles_cap = 0;
 }
 
-static void make_geom(const pcr_cloud *cloud, double h, uint64_t max_cells, GridGeom &G, double &h_out,
-                      uint64_t &cells) {
+void make_geom(const double lo[3], const double hi[3], double h, uint64_t max_cells, GridGeom &G, double &h_out,
+               uint64_t &cells) {
     for (;;) {
         cells = 1;
         for (int a = 0; a < 3; ++a) {
-            const double ext = cloud->hi[a] - cloud->lo[a];
+            const double ext = hi[a] - lo[a];
             double g = floor(ext / h) + 1.0;
             if (!(g >= 1.0)) g = 1.0;
             if (g > 2097152.0) g = 2097152.0;
             G.g[a] = (int)g;
-            G.lo[a] = cloud->lo[a];
+            G.lo[a] = lo[a];
             cells *= (uint64_t)G.g[a];
         }
         if (cells <= max_cells) break;
@@ -797,6 +877,130 @@ static void make_geom(const pcr_cloud *cloud, double h, uint64_t max_cells, Grid
     G.inv_h = 1.0 / h;
     h_out = h;
 }
+
+// one trial of the histogram at a given cell size: fills counts (device) and the occupancy statistics
+int histogram_trial(pcr_ctx *ctx, const pcr_cloud *cloud, const uint8_t *lvl_d, uint8_t level, LevelBuild &B,
+                    unsigned long long *stats_d) {
+    PCR_HIP(hipMemsetAsync(B.counts_d, 0, sizeof(uint32_t) * (B.cells + 1), ctx->stream));
+    PCR_HIP(hipMemsetAsync(stats_d, 0, sizeof(unsigned long long) * 2, ctx->stream));
+    hipLaunchKernelGGL(cell_histogram_kernel, dim3(grid_blocks(cloud->n)), dim3(256), 0, ctx->stream, cloud->xyz_d,
+                       cloud->n, B.G, lvl_d, level, B.counts_d);
+    const uint32_t tiles = (uint32_t)((B.cells + SCAN_TILE - 1) / SCAN_TILE);
+    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(tiles), dim3(256), 0, ctx->stream, B.counts_d, B.cells,
+                       B.tile_sums_d, stats_d);
+    PCR_HIP(hipMemcpyAsync(B.stats_h, stats_d, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(hipStreamSynchronize(ctx->stream));
+    return PCR_OK;
+}
+
+// Chooses the cell edge for the n_l points of one level inside [lo,hi] -- aiming at target_occupancy points per
+// OCCUPIED cell -- and leaves the histogram of the final choice in B.counts_d (tile sums in B.tile_sums_d).
+int choose_cells(pcr_ctx *ctx, const pcr_cloud *cloud, const uint8_t *lvl_d, uint8_t level, uint32_t n_l,
+                 const double lo[3], const double hi[3], const pcr_index_params &P, double h_min,
+                 unsigned long long *stats_d, LevelBuild &B) {
+    double vol = 1.0;
+    int live = 0;
+    for (int a = 0; a < 3; ++a) {
+        const double ext = hi[a] - lo[a];
+        if (ext > 0) {
+            vol *= ext;
+            ++live;
+        }
+    }
+    double h;
+    if (P.cell_size > 0)
+        h = P.cell_size;
+    else if (live == 0)
+        h = 1.0;
+    else
+        h = pow(vol * P.target_occupancy / (double)n_l, 1.0 / live);  // volume-uniform first guess
+    if (!(h > 0) || !isfinite(h)) h = 1.0;
+    if (h < h_min) h = h_min > 0 ? h_min : 1.0;
+    for (int trial = 0; trial < 8; ++trial) {
+        double h_used;
+        make_geom(lo, hi, h, P.max_cells, B.G, h_used, B.cells);
+        h = h_used;
+        if (B.cells + 1 > B.counts_cap) {
+            if (B.counts_d) hipFree(B.counts_d);
+            B.counts_d = nullptr;
+            B.counts_cap = 0;
+            PCR_HIP(hipMalloc(&B.counts_d, sizeof(uint32_t) * (B.cells + 1)));
+            B.counts_cap = B.cells + 1;
+        }
+        const size_t tiles = (B.cells + SCAN_TILE - 1) / SCAN_TILE + 1;
+        if (tiles > B.tiles_cap) {
+            if (B.tile_sums_d) hipFree(B.tile_sums_d);
+            B.tile_sums_d = nullptr;
+            B.tiles_cap = 0;
+            PCR_HIP(hipMalloc(&B.tile_sums_d, sizeof(uint32_t) * tiles));
+            B.tiles_cap = tiles;
+        }
+        int rc = histogram_trial(ctx, cloud, lvl_d, level, B, stats_d);
+        if (rc != PCR_OK) return rc;
+        if (P.cell_size > 0) break;
+        const double occ = (double)n_l / (double)(B.stats_h[0] ? B.stats_h[0] : 1);
+        const double ratio = P.target_occupancy / occ;
+        if (ratio < 1.35 && ratio > 0.74) break;  // close enough
+        if (ratio < 1.0 && B.cells == 1) break;
+        // points on a surface: occupancy ~ h^2.  (A volume converges too, in a damped oscillation.)
+        double nh = h * sqrt(ratio);
+        if (nh < h_min) nh = h_min;
+        if (nh == h) break;
+        // growing h is always possible; shrinking may hit max_cells, in which case make_geom undoes it
+        if (trial == 7) break;
+        h = nh;
+    }
+    B.h = h;
+    return PCR_OK;
+}
+
+// Splitting rule of the nested levels.  A level is split when a noticeable share of its points sits in cells far
+// above the occupancy the cell size was chosen for (the cell size follows the MEAN; a LiDAR sweep's density varies
+// by four orders of magnitude) and those cells are confined to a part of the level's box.  The box of the cells
+// above a lower mark goes down one level, where it gets a cell size of its own.
+constexpr uint32_t SPLIT_TRIGGER = 64;     // "far too full"
+constexpr uint32_t SPLIT_BOX_MARK = 32;    // the inner box spans the cells above this
+constexpr uint32_t SPLIT_MIN_POINTS = 8192;
+constexpr double SPLIT_MIN_SHARE = 0.05;   // of the level's points in far-too-full cells
+constexpr double SPLIT_MAX_VOLUME = 0.5;   // inner box / level box
+
+// Decides on a split of the level whose histogram is in B; on yes, fills `inner` with the box to hand down.
+int find_dense_box(pcr_ctx *ctx, const LevelBuild &B, uint32_t n_l, const double lo[3], const double hi[3],
+                   uint32_t *stats16_d, Box3 &inner, bool &split) {
+    split = false;
+    uint32_t init[16], got[16];
+    for (int t = 0; t < 2; ++t) {
+        init[t * 8] = 0;
+        for (int a = 0; a < 3; ++a) {
+            init[t * 8 + 1 + a] = 0xffffffffu;
+            init[t * 8 + 4 + a] = 0;
+        }
+        init[t * 8 + 7] = 0;
+    }
+    PCR_HIP(hipMemcpyAsync(stats16_d, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(heavy_stats_kernel, dim3(grid_blocks(B.cells, 256, 4096)), dim3(256), 0, ctx->stream,
+                       (const uint32_t *)B.counts_d, B.cells, (uint32_t)B.G.g[0], (uint32_t)B.G.g[1], SPLIT_BOX_MARK,
+                       SPLIT_TRIGGER, stats16_d);
+    PCR_HIP(hipMemcpyAsync(got, stats16_d, sizeof got, hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(hipStreamSynchronize(ctx->stream));
+    const double share = (double)got[8] / (double)n_l;
+    if (got[8] < SPLIT_MIN_POINTS || share < SPLIT_MIN_SHARE) return PCR_OK;
+    for (int t = 0; t < 2 && !split; ++t) {  // the generous box first, the tight one if that spans too much
+        double frac = 1.0;
+        for (int a = 0; a < 3; ++a) {
+            inner.lo[a] = B.G.lo[a] + (double)got[t * 8 + 1 + a] * B.h;
+            inner.hi[a] = B.G.lo[a] + (double)(got[t * 8 + 4 + a] + 1u) * B.h;
+            if (got[t * 8 + 1 + a] == 0) inner.lo[a] = lo[a];
+            if ((int)got[t * 8 + 4 + a] >= B.G.g[a] - 1 || inner.hi[a] > hi[a]) inner.hi[a] = hi[a];
+            const double ext = hi[a] - lo[a];
+            if (ext > 0) frac *= (inner.hi[a] - inner.lo[a]) / ext;
+        }
+        split = frac <= SPLIT_MAX_VOLUME;
+    }
+    return PCR_OK;
+}
+
+}  // namespace
 
 int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params *params, pcr_index **out) {
     PCR_REQUIRE(ctx && cloud && out, "pcr_index_build: NULL argument");
@@ -813,6 +1017,8 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
     if (P.max_cells == 0) P.max_cells = 1ull << 30;
     if (P.max_cells > (1ull << 32) - 8) P.max_cells = (1ull << 32) - 8;
     if (P.brute_max_points == 0) P.brute_max_points = 2048;
+    if (P.max_levels == 0 || P.max_levels > (uint32_t)PCR_MAX_LEVELS) P.max_levels = PCR_MAX_LEVELS;
+    if (P.cell_size > 0) P.max_levels = 1;  // a fixed cell edge means one uniform grid
     int kind = P.kind;
     PCR_REQUIRE(kind == PCR_INDEX_AUTO || kind == PCR_INDEX_GRID || kind == PCR_INDEX_BRUTE,
                 "pcr_index_build: unknown kind %d", kind);
@@ -826,8 +1032,11 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
     ix->kind = kind;
     ix->n = n;
     int rc = PCR_OK;
-    uint32_t *counts_d = nullptr, *tile_sums_d = nullptr, *cursor_d = nullptr;
+    LevelBuild B;
+    memset(&B, 0, sizeof B);
+    uint32_t *cursor_d = nullptr, *stats16_d = nullptr;
     unsigned long long *stats_d = nullptr;
+    uint8_t *lvl_d = nullptr;
 #define BUILD_HIP(call)                                                                             \
     do {                                                                                            \
         hipError_t e__ = (call);                                                                    \
@@ -837,6 +1046,11 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
             goto fail;                                                                              \
         }                                                                                           \
     } while (0)
+#define BUILD_RC(call)            \
+    do {                          \
+        rc = (call);              \
+        if (rc != PCR_OK) goto fail; \
+    } while (0)
 
     BUILD_HIP(hipMalloc(&ix->pts_d, sizeof(Pt4) * (size_t)n));
     BUILD_HIP(hipMalloc(&ix->tpts_d, sizeof(Pt4) * (size_t)n));
@@ -844,23 +1058,32 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
     BUILD_HIP(hipMalloc(&ix->order_d, sizeof(uint32_t) * (size_t)n));
 
     {
-        GridView &V = ix->view;
+        MultiView &M = ix->view;
         double scale = 0, maxext = 0;
         for (int a = 0; a < 3; ++a) {
-            V.lo[a] = cloud->lo[a];
-            V.hi[a] = cloud->hi[a];
+            M.lo[a] = cloud->lo[a];
+            M.hi[a] = cloud->hi[a];
             scale = fmax(scale, fmax(fabs(cloud->lo[a]), fabs(cloud->hi[a])));
             maxext = fmax(maxext, cloud->hi[a] - cloud->lo[a]);
         }
-        V.margin = 9.094947017729282e-13 * (scale + maxext);  // 2^-40 of the coordinate scale
-        V.n = n;
-        V.pts = ix->pts_d;
-        V.pos_of = ix->pos_of_d;
-        V.cs = nullptr;
-        V.h = V.inv_h = 1.0;
-        V.g[0] = V.g[1] = V.g[2] = 1;
+        const double margin = 9.094947017729282e-13 * (scale + maxext);  // 2^-40 of the coordinate scale
+        M.levels = 1;
+        M.n = n;
+        M.all = ix->pts_d;
+        M.pos_of = ix->pos_of_d;
 
         if (kind == PCR_INDEX_BRUTE) {
+            GridView &V = M.v[0];
+            for (int a = 0; a < 3; ++a) {
+                V.lo[a] = cloud->lo[a];
+                V.hi[a] = cloud->hi[a];
+            }
+            V.margin = margin;
+            V.n = n;
+            V.pts = ix->pts_d;
+            V.cs = nullptr;
+            V.h = V.inv_h = 1.0;
+            V.g[0] = V.g[1] = V.g[2] = 1;
             hipLaunchKernelGGL(pack_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, cloud->xyz_d, n,
                                ix->pts_d, ix->pos_of_d);
             BUILD_HIP(hipMemcpyAsync(ix->order_d, ix->pos_of_d, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice,
@@ -873,122 +1096,137 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
             ix->info.cell_size = 0;
             ix->info.mean_occupancy = n;
             ix->info.max_occupancy = n;
+            ix->info.levels = 1;
             ix->info.device_bytes = (sizeof(Pt4) * 2 + 4) * (uint64_t)n;
             *out = ix;
             return PCR_OK;
         }
 
-        // ---- choose the cell edge: aim at target_occupancy points per OCCUPIED cell ----
-        double ext[3], vol = 1.0;
-        int live = 0;
-        for (int a = 0; a < 3; ++a) {
-            ext[a] = cloud->hi[a] - cloud->lo[a];
-            if (ext[a] > 0) {
-                vol *= ext[a];
-                ++live;
-            }
-        }
-        double h;
-        if (P.cell_size > 0)
-            h = P.cell_size;
-        else if (live == 0)
-            h = 1.0;
-        else
-            h = pow(vol * P.target_occupancy / (double)n, 1.0 / live);  // volume-uniform first guess
-        if (!(h > 0) || !isfinite(h)) h = 1.0;
         // never finer than 2^-20 of the scale: keeps the safety margin (2^-40) far below a cell
         const double h_min = (scale + maxext) * 9.5367431640625e-07;
-        if (h < h_min) h = h_min > 0 ? h_min : 1.0;
-
-        GridGeom G;
-        uint64_t cells = 0;
-        unsigned long long stats_h[2] = {0, 0};
         BUILD_HIP(hipMalloc(&stats_d, sizeof(unsigned long long) * 2));
-        size_t counts_cap = 0;
-        for (int trial = 0; trial < 8; ++trial) {
-            double h_used;
-            make_geom(cloud, h, P.max_cells, G, h_used, cells);
-            h = h_used;
-            if (cells + 1 > counts_cap) {
-                if (counts_d) hipFree(counts_d);
-                if (tile_sums_d) hipFree(tile_sums_d);
-                counts_d = tile_sums_d = nullptr;
-                counts_cap = cells + 1;
-                BUILD_HIP(hipMalloc(&counts_d, sizeof(uint32_t) * counts_cap));
-                BUILD_HIP(hipMalloc(&tile_sums_d, sizeof(uint32_t) * ((cells + SCAN_TILE - 1) / SCAN_TILE + 1)));
-            }
-            rc = histogram_trial(ctx, cloud, G, cells, counts_d, tile_sums_d, stats_d, stats_h);
-            if (rc != PCR_OK) goto fail;
-            if (P.cell_size > 0) break;
-            const double occ = (double)n / (double)(stats_h[0] ? stats_h[0] : 1);
-            const double ratio = P.target_occupancy / occ;
-            if (ratio < 1.35 && ratio > 0.74) break;  // close enough
-            if (ratio < 1.0 && cells == 1) break;
-            // points on a surface: occupancy ~ h^2.  (A volume converges too, in a damped oscillation.)
-            double nh = h * sqrt(ratio);
-            if (nh < h_min) nh = h_min;
-            if (nh == h) break;
-            // growing h is always possible; shrinking may hit max_cells, in which case make_geom undoes it
-            if (trial == 7) break;
-            h = nh;
-        }
+        BUILD_HIP(hipMalloc(&stats16_d, sizeof(uint32_t) * 16));
 
-        // ---- scan + scatter ----
-        {
-            const uint32_t tiles = (uint32_t)((cells + SCAN_TILE - 1) / SCAN_TILE);
-            hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, tile_sums_d, tiles);
-            hipLaunchKernelGGL(scan_apply_kernel, dim3(tiles), dim3(256), 0, ctx->stream, counts_d, cells,
-                               tile_sums_d, n);
-            BUILD_HIP(hipMalloc(&cursor_d, sizeof(uint32_t) * cells));
-            BUILD_HIP(hipMemcpyAsync(cursor_d, counts_d, sizeof(uint32_t) * cells, hipMemcpyDeviceToDevice,
-                                     ctx->stream));
-            hipLaunchKernelGGL(scatter_kernel, dim3(grid_blocks(n)), dim3(256), 0, ctx->stream, cloud->xyz_d, n, G,
-                               cursor_d, ix->pts_d);
-            hipLaunchKernelGGL(cell_order_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream,
-                               counts_d, cells, ix->pts_d);
-            if (stats_h[1] > PCR_HEAVY_CELL) {
-                rc = sort_heavy_cells(ctx, counts_d, cells, n, ix->pts_d, ix->tpts_d);
-                if (rc != PCR_OK) goto fail;
-            }
-            hipLaunchKernelGGL(pos_of_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ix->pts_d, n,
-                               ix->pos_of_d);
-            BUILD_HIP(hipStreamSynchronize(ctx->stream));
-            BUILD_HIP(hipGetLastError());
+        double lo[3], hi[3];  // box of the level being built
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = cloud->lo[a];
+            hi[a] = cloud->hi[a];
         }
-        ix->cs_d = counts_d;
-        counts_d = nullptr;
-        V.cs = ix->cs_d;
-        V.h = h;
-        V.inv_h = G.inv_h;
-        for (int a = 0; a < 3; ++a) V.g[a] = G.g[a];
-        // processing order of "all samples": by grid brick, so that a wave's 64 queries share a small box
-        rc = brick_order(ctx, V, ix->pts_d, nullptr, n, ix->order_d, true);
-        if (rc != PCR_OK) goto fail;
+        uint32_t n_l = n, off = 0;
+        uint64_t occupied_total = 0, cells_total = 0;
+        uint32_t max_occ = 0;
+        for (int l = 0;; ++l) {
+            const uint8_t *filter = lvl_d;  // NULL while nothing has been split off: every point is level 0
+            BUILD_RC(choose_cells(ctx, cloud, filter, (uint8_t)l, n_l, lo, hi, P, h_min, stats_d, B));
+            uint32_t n_inner = 0;
+            if (l + 1 < (int)P.max_levels && n_l >= SPLIT_MIN_POINTS && B.stats_h[1] > SPLIT_TRIGGER) {
+                Box3 inner;
+                bool split = false;
+                BUILD_RC(find_dense_box(ctx, B, n_l, lo, hi, stats16_d, inner, split));
+                if (split) {
+                    if (!lvl_d) {
+                        BUILD_HIP(hipMalloc(&lvl_d, n));
+                        BUILD_HIP(hipMemsetAsync(lvl_d, 0, n, ctx->stream));
+                    }
+                    BUILD_HIP(hipMemsetAsync(stats16_d, 0, sizeof(uint32_t), ctx->stream));
+                    hipLaunchKernelGGL(assign_level_kernel, dim3(grid_blocks(n)), dim3(256), 0, ctx->stream, cloud->xyz_d, n,
+                                       inner, lvl_d, (uint8_t)l, stats16_d);
+                    BUILD_HIP(hipMemcpyAsync(&n_inner, stats16_d, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+                    BUILD_HIP(hipStreamSynchronize(ctx->stream));
+                    if (n_inner >= n_l) {
+                        // cannot happen (the inner box is at most half the level's box, whose faces all touch a
+                        // point); undo rather than build an empty level
+                        set_last_error("pcr_index_build: level split moved every point");
+                        rc = PCR_E_HIP;
+                        goto fail;
+                    }
+                    n_l -= n_inner;
+                    // the level keeps the sparse remainder: choose its cells again
+                    BUILD_RC(choose_cells(ctx, cloud, lvl_d, (uint8_t)l, n_l, lo, hi, P, h_min, stats_d, B));
+                }
+            }
+            // ---- scan + scatter into the level's segment [off, off + n_l) ----
+            {
+                const uint32_t tiles = (uint32_t)((B.cells + SCAN_TILE - 1) / SCAN_TILE);
+                Pt4 *seg = ix->pts_d + off;
+                hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, B.tile_sums_d, tiles);
+                hipLaunchKernelGGL(scan_apply_kernel, dim3(tiles), dim3(256), 0, ctx->stream, B.counts_d, B.cells,
+                                   B.tile_sums_d, n_l);
+                BUILD_HIP(hipMalloc(&cursor_d, sizeof(uint32_t) * B.cells));
+                BUILD_HIP(hipMemcpyAsync(cursor_d, B.counts_d, sizeof(uint32_t) * B.cells, hipMemcpyDeviceToDevice,
+                                         ctx->stream));
+                hipLaunchKernelGGL(scatter_kernel, dim3(grid_blocks(n)), dim3(256), 0, ctx->stream, cloud->xyz_d, n, B.G,
+                                   (const uint8_t *)lvl_d, (uint8_t)l, cursor_d, seg);
+                hipLaunchKernelGGL(cell_order_kernel, dim3((unsigned)((B.cells + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   (const uint32_t *)B.counts_d, B.cells, seg);
+                if (B.stats_h[1] > PCR_HEAVY_CELL) BUILD_RC(sort_heavy_cells(ctx, B.counts_d, B.cells, n_l, seg, ix->tpts_d + off));
+                BUILD_HIP(hipStreamSynchronize(ctx->stream));
+                BUILD_HIP(hipGetLastError());
+                hipFree(cursor_d);
+                cursor_d = nullptr;
+            }
+            GridView &V = M.v[l];
+            for (int a = 0; a < 3; ++a) {
+                V.lo[a] = lo[a];
+                V.hi[a] = hi[a];
+                V.g[a] = B.G.g[a];
+            }
+            V.margin = margin;
+            V.n = n_l;
+            V.pts = ix->pts_d + off;
+            V.cs = B.counts_d;
+            V.h = B.h;
+            V.inv_h = B.G.inv_h;
+            ix->cs_d[l] = B.counts_d;  // the index owns the table from here on
+            ix->cells[l] = B.cells;
+            B.counts_d = nullptr;
+            B.counts_cap = 0;
+            M.levels = l + 1;
+            // processing order of "all samples": by grid brick, so that a wave's 64 queries share a small box
+            BUILD_RC(brick_order(ctx, V, V.pts, nullptr, n_l, ix->order_d + off, true, off));
+            BUILD_HIP(hipStreamSynchronize(ctx->stream));
+            if (l == 0) {
+                for (int a = 0; a < 3; ++a) ix->info.dims[a] = (uint32_t)B.G.g[a];
+                ix->info.cell_size = B.h;
+            }
+            cells_total += B.cells;
+            occupied_total += B.stats_h[0];
+            max_occ = max_occ > (uint32_t)B.stats_h[1] ? max_occ : (uint32_t)B.stats_h[1];
+            if (n_inner == 0) break;
+            // ---- the next level: the points handed down, in their own (tight) box ----
+            off += n_l;
+            n_l = n_inner;
+            BUILD_RC(compute_bounds(ctx, cloud->xyz_d, n, lvl_d, (uint8_t)(l + 1), lo, hi));
+        }
+        hipLaunchKernelGGL(pos_of_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ix->pts_d, n, ix->pos_of_d);
         BUILD_HIP(hipStreamSynchronize(ctx->stream));
+        BUILD_HIP(hipGetLastError());
         ix->info.kind = kind;
         ix->info.n = n;
-        for (int a = 0; a < 3; ++a) ix->info.dims[a] = (uint32_t)G.g[a];
-        ix->info.cells = cells;
-        ix->info.occupied_cells = stats_h[0];
-        ix->info.cell_size = h;
-        ix->info.mean_occupancy = (double)n / (double)(stats_h[0] ? stats_h[0] : 1);
-        ix->info.max_occupancy = (uint32_t)stats_h[1];
-        ix->info.device_bytes = (sizeof(Pt4) * 2 + 4) * (uint64_t)n + 4 * (cells + 1);
+        ix->info.cells = cells_total;
+        ix->info.occupied_cells = occupied_total;
+        ix->info.mean_occupancy = (double)n / (double)(occupied_total ? occupied_total : 1);
+        ix->info.max_occupancy = max_occ;
+        ix->info.levels = (uint32_t)M.levels;
+        ix->info.device_bytes = (sizeof(Pt4) * 2 + 8) * (uint64_t)n + 4 * (cells_total + M.levels);
     }
-    if (tile_sums_d) hipFree(tile_sums_d);
-    if (cursor_d) hipFree(cursor_d);
+    release(B);
     if (stats_d) hipFree(stats_d);
+    if (stats16_d) hipFree(stats16_d);
+    if (lvl_d) hipFree(lvl_d);
     *out = ix;
     return PCR_OK;
 
 fail:
-    if (counts_d) hipFree(counts_d);
-    if (tile_sums_d) hipFree(tile_sums_d);
+    release(B);
     if (cursor_d) hipFree(cursor_d);
     if (stats_d) hipFree(stats_d);
+    if (stats16_d) hipFree(stats16_d);
+    if (lvl_d) hipFree(lvl_d);
     pcr_index_free(ix);
     return rc;
 #undef BUILD_HIP
+#undef BUILD_RC
 }
 
 int pcr_index_get_info(const pcr_index *ix, pcr_index_info *info) {

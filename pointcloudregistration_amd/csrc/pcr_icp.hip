@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) transform_kernel(const Pt4 *__restrict__ 
 }
 
 struct StepArgs {
-    GridView src, tgt;
+    MultiView src, tgt;
     const Pt4 *tsrc;             // transformed source, parallel to src.pts
     const uint32_t *src_pos_of;  // original index -> position in src.pts
     const uint32_t *src_order;   // positions of src.pts in brick order (processing order of "all samples")
@@ -134,7 +134,9 @@ __device__ __forceinline__ void accumulate(double (&acc)[17], bool keep, double 
     acc[16] = keep ? dF : 0.0;
 }
 
-template <int KC>
+// MULTI: either index has more than one level (clouds of very uneven density); the single-level instance is the
+// plain search on level 0, with none of the level loop in its code.
+template <int KC, bool MULTI>
 __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(StepArgs A) {
     const StepDyn *__restrict__ dynp = A.dyn;
     if (dynp->done) return;  // uniform over the grid
@@ -154,10 +156,10 @@ __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(Step
             slot = t;
         } else {
             pos = A.src_order[A.sample_begin + t];  // brick order: a wave's samples are neighbours in space
-            orig = (uint32_t)A.src.pts[pos].w;
+            orig = (uint32_t)A.src.all[pos].w;
             slot = orig;
         }
-        const Pt4 s = A.src.pts[pos];
+        const Pt4 s = A.src.all[pos];
         xform(D.M, s.x, s.y, s.z, px, py, pz);  // CurSrcPoint = R*s + T (:86)
     }
     // ---- forward: K-th nearest target point of p (:89-92) ----
@@ -167,8 +169,14 @@ __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(Step
     top.init(fmax_d2);
     __shared__ uint2 rowtab[9][256];  // per-lane row table of the ring walk (knn_device.h)
     uint2 *my_rows = &rowtab[0][threadIdx.x];
-    if (fin)
-        lane_search<KC>(A.tgt, A.tgt.pts, px, py, pz, px, py, pz, fmax_d2, 1.0 - 1.8189894035458565e-12, 0.0, top, my_rows);
+    if (fin) {
+        if constexpr (MULTI)
+            multi_lane_search<KC>(A.tgt, A.tgt.all, px, py, pz, px, py, pz, fmax_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
+                                  my_rows);
+        else
+            lane_search<KC>(A.tgt.v[0], A.tgt.all, px, py, pz, px, py, pz, fmax_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
+                            my_rows);
+    }
     double dF;
     uint32_t j;
     top.slot(A.k, dF, j);  // NeighborSet.back() = K-th nearest (:91-92)
@@ -180,7 +188,7 @@ __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(Step
     const bool need_rev = found && (passF || A.exact);
     double qx = 0, qy = 0, qz = 0, sx = 0, sy = 0, sz = 0;
     if (need_rev) {
-        const Pt4 qpt = A.tgt.pts[A.tgt.pos_of[j]];
+        const Pt4 qpt = A.tgt.all[A.tgt.pos_of[j]];
         qx = qpt.x;
         qy = qpt.y;
         qz = qpt.z;
@@ -193,8 +201,14 @@ __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(Step
     rt.d[0] = dF;
     rt.idx[0] = orig;
     const bool rev_active = need_rev && isfinite(sx) && isfinite(sy) && isfinite(sz);
-    if (rev_active)
-        lane_search<1>(A.src, A.tsrc, qx, qy, qz, sx, sy, sz, PCR_INF, D.rev_bound_scale, D.rev_extra_margin, rt, my_rows);
+    if (rev_active) {
+        if constexpr (MULTI)
+            multi_lane_search<1>(A.src, A.tsrc, qx, qy, qz, sx, sy, sz, PCR_INF, D.rev_bound_scale, D.rev_extra_margin, rt,
+                                 my_rows);
+        else
+            lane_search<1>(A.src.v[0], A.tsrc, qx, qy, qz, sx, sy, sz, PCR_INF, D.rev_bound_scale, D.rev_extra_margin, rt,
+                           my_rows);
+    }
     uint32_t r = PCR_NO_INDEX;
     bool keep = false;
     if (need_rev) {
@@ -233,10 +247,10 @@ __global__ void __launch_bounds__(256) icp_step_brute_kernel(StepArgs A) {
             slot = t;
         } else {
             pos = A.sample_begin + t;
-            orig = (uint32_t)A.src.pts[pos].w;
+            orig = (uint32_t)A.src.all[pos].w;
             slot = orig;
         }
-        const Pt4 s = A.src.pts[pos];
+        const Pt4 s = A.src.all[pos];
         xform(D.M, s.x, s.y, s.z, px, py, pz);
     }
     const bool fin = live && isfinite(px) && isfinite(py) && isfinite(pz);
@@ -244,7 +258,7 @@ __global__ void __launch_bounds__(256) icp_step_brute_kernel(StepArgs A) {
     top.init();
     for (uint32_t base = 0; base < A.tgt.n; base += 512) {
         const int cnt = (int)min(512u, A.tgt.n - base);
-        for (int u = threadIdx.x; u < cnt; u += 256) tile[u] = A.tgt.pts[base + u];
+        for (int u = threadIdx.x; u < cnt; u += 256) tile[u] = A.tgt.all[base + u];
         __syncthreads();
         if (fin) tile_scan<KC>(tile, cnt, px, py, pz, top);
         __syncthreads();
@@ -256,7 +270,7 @@ __global__ void __launch_bounds__(256) icp_step_brute_kernel(StepArgs A) {
     const bool passF = found && dF < A.thr_fwd;
     double qx = 0, qy = 0, qz = 0;
     if (found) {
-        const Pt4 qpt = A.tgt.pts[A.tgt.pos_of[j]];
+        const Pt4 qpt = A.tgt.all[A.tgt.pos_of[j]];
         qx = qpt.x;
         qy = qpt.y;
         qz = qpt.z;
@@ -471,8 +485,10 @@ static void launch_step_kernels(pcr_ctx *ctx, const pcr_index *src, const StepAr
     }
 #define LAUNCH_STEP(KC)                                                                                \
     do {                                                                                               \
-        if (src->kind == PCR_INDEX_GRID)                                                               \
-            hipLaunchKernelGGL(icp_step_grid_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, A);      \
+        if (src->kind == PCR_INDEX_GRID && (A.src.levels > 1 || A.tgt.levels > 1))                    \
+            hipLaunchKernelGGL((icp_step_grid_kernel<KC, true>), dim3(nb), dim3(256), 0, ctx->stream, A); \
+        else if (src->kind == PCR_INDEX_GRID)                                                          \
+            hipLaunchKernelGGL((icp_step_grid_kernel<KC, false>), dim3(nb), dim3(256), 0, ctx->stream, A); \
         else                                                                                           \
             hipLaunchKernelGGL(icp_step_brute_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, A);     \
     } while (0)

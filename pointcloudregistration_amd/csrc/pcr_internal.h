@@ -43,12 +43,27 @@ struct __attribute__((aligned(32))) Pt4 {
 struct GridView {
     const Pt4 *pts;       // [n] in cell order (GRID) or in original order (BRUTE)
     const uint32_t *cs;   // [cells+1] exclusive cell starts; NULL for BRUTE
-    const uint32_t *pos_of;  // [n] original index -> position in pts
     double lo[3], hi[3];  // bounds of the points
     double h, inv_h;      // cell edge
     double margin;        // absolute safety margin on face distances, ~2^-40 * coordinate scale
     int g[3];             // grid dimensions
     uint32_t n;
+};
+
+// An index is a small stack of such grids over DISJOINT subsets of the cloud ("levels"): level 0 spans the whole
+// cloud, every further level covers the box where the level before it is much denser than elsewhere, with a cell
+// size of its own (a LiDAR sweep's density falls by orders of magnitude with range; one cell size cannot fit
+// that).  All levels share one point array (each owns a contiguous segment), one pos_of table and one transformed
+// copy.  A uniform cloud has one level.  A search visits the levels whose box can still hold a better point, carrying
+// its top-K from one to the next -- exact, because the union of exact searches over a partition is exact.
+constexpr int PCR_MAX_LEVELS = 6;
+struct MultiView {
+    int levels;
+    uint32_t n;              // all points
+    const Pt4 *all;          // [n] every level's segment, level 0 first
+    const uint32_t *pos_of;  // [n] original index -> position in `all`
+    double lo[3], hi[3];     // bounds of the whole cloud
+    GridView v[PCR_MAX_LEVELS];
 };
 
 }  // namespace pcr
@@ -110,8 +125,9 @@ namespace pcr {
 void *ctx_scratch(pcr_ctx *ctx, int slot, size_t bytes);
 // positions [0,n) ordered by the Morton key of the (>=4x4x4-cell) brick their point falls in; exactly one of
 // pts / xyz_aos is non-NULL.  deterministic: order inside a brick made ascending (index build only).
+// The positions written are base + i (a level's segment of a multi-level index starts at `base`).
 int brick_order(pcr_ctx *ctx, const GridView &g, const Pt4 *pts, const double *xyz_aos, uint32_t n,
-                uint32_t *order_d, bool deterministic);
+                uint32_t *order_d, bool deterministic, uint32_t base = 0);
 // cells above this many points are ordered by the segmented sort (pcr_sort.hip), the others by one thread each
 #define PCR_HEAVY_CELL 32u
 // orders the points of every heavy cell by (x, original index); tmp is scratch of the same size as pts
@@ -135,9 +151,10 @@ struct pcr_index {
     uint32_t n;
     pcr::Pt4 *pts_d;    // [n] cell order (GRID) / original order (BRUTE)
     pcr::Pt4 *tpts_d;   // [n] same order, transformed by the current (R,T) -- scratch of the ICP step
-    uint32_t *cs_d;     // [cells+1]
     uint32_t *pos_of_d; // [n] original index -> position in pts_d
     uint32_t *order_d;  // [n] positions in pts_d ordered by grid brick: the processing order of "all samples"
-    pcr::GridView view;
+    pcr::MultiView view;
+    uint32_t *cs_d[pcr::PCR_MAX_LEVELS];    // [cells+1] of every level, positions relative to the level's segment
+    uint64_t cells[pcr::PCR_MAX_LEVELS];
     pcr_index_info info;
 };

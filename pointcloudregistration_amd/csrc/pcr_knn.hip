@@ -26,8 +26,8 @@ __device__ __forceinline__ void write_result(const TopK<KC> &top, int k, int ord
 
 // One lane per query, pruned ring walk (knn_device.h).
 // order (nullable): processing order of the queries (by grid brick), results go to the query's own row.
-template <int KC>
-__global__ void __launch_bounds__(256) knn_grid_kernel(GridView g, const double *__restrict__ q,
+template <int KC, bool MULTI>
+__global__ void __launch_bounds__(256) knn_grid_kernel(MultiView g, const double *__restrict__ q,
                                                        const uint32_t *__restrict__ order, uint32_t nq, int k,
                                                        int order_out, double max_d2, uint32_t *__restrict__ out_idx,
                                                        double *__restrict__ out_d2) {
@@ -44,9 +44,14 @@ __global__ void __launch_bounds__(256) knn_grid_kernel(GridView g, const double 
     TopK<KC> top;
     top.init(max_d2);
     __shared__ uint2 rowtab[9][256];
-    if (active)
-        lane_search<KC>(g, g.pts, qx, qy, qz, qx, qy, qz, max_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
-                        &rowtab[0][threadIdx.x]);
+    if (active) {
+        if constexpr (MULTI)
+            multi_lane_search<KC>(g, g.all, qx, qy, qz, qx, qy, qz, max_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
+                                  &rowtab[0][threadIdx.x]);
+        else
+            lane_search<KC>(g.v[0], g.all, qx, qy, qz, qx, qy, qz, max_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
+                            &rowtab[0][threadIdx.x]);
+    }
     if (live)
         write_result<KC>(top, k, order_out, max_d2, out_idx + (size_t)i * k, out_d2 ? out_d2 + (size_t)i * k : nullptr);
 }
@@ -91,9 +96,12 @@ template <int KC>
 static void launch_knn(pcr_ctx *ctx, const pcr_index *ix, const double *q_d, const uint32_t *qorder, uint32_t nq,
                        uint32_t k, int order, double max_d2, uint32_t *oi_d, double *od_d) {
     const uint32_t nb = (nq + 255) / 256;
-    if (ix->kind == PCR_INDEX_GRID)
-        hipLaunchKernelGGL(knn_grid_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, ix->view, q_d, qorder, nq, (int)k,
-                           order, max_d2, oi_d, od_d);
+    if (ix->kind == PCR_INDEX_GRID && ix->view.levels > 1)
+        hipLaunchKernelGGL((knn_grid_kernel<KC, true>), dim3(nb), dim3(256), 0, ctx->stream, ix->view, q_d, qorder, nq,
+                           (int)k, order, max_d2, oi_d, od_d);
+    else if (ix->kind == PCR_INDEX_GRID)
+        hipLaunchKernelGGL((knn_grid_kernel<KC, false>), dim3(nb), dim3(256), 0, ctx->stream, ix->view, q_d, qorder, nq,
+                           (int)k, order, max_d2, oi_d, od_d);
     else
         hipLaunchKernelGGL(knn_brute_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, ix->pts_d, ix->n, q_d, nq,
                            (int)k, order, max_d2, oi_d, od_d);
@@ -126,7 +134,7 @@ int pcr_knn_d(pcr_ctx *ctx, const pcr_index *ix, const double *q_d, uint32_t nq,
     if (ix->kind == PCR_INDEX_GRID && nq >= 2048 && g_tune[3] == 0) {
         uint32_t *o = (uint32_t *)ctx_scratch(ctx, 4, sizeof(uint32_t) * (size_t)nq);
         if (!o) return PCR_E_NOMEM;
-        int rc = coarse_query_order(ctx, ix->view, q_d, nq, o);
+        int rc = coarse_query_order(ctx, ix->view.v[0], q_d, nq, o);
         if (rc != PCR_OK) return rc;
         qorder = o;
     }

@@ -21,12 +21,17 @@
 namespace pcr {
 
 template <int KC>
-__device__ __forceinline__ double sq_dist_to_centroid(const GridView &g, double x, double y, double z, int k,
-                                                      double msd) {
+__device__ __forceinline__ double sq_dist_to_centroid(const MultiView &g, double x, double y, double z, int k,
+                                                      double msd, uint2 *rowtab) {
     TopK<KC> top;
     top.init();
-    if (isfinite(x) && isfinite(y) && isfinite(z))
-        grid_search<KC>(g, g.pts, x, y, z, x, y, z, PCR_INF, 1.0 - 1.8189894035458565e-12, 0.0, top);
+    if (isfinite(x) && isfinite(y) && isfinite(z)) {
+        const double bs = 1.0 - 1.8189894035458565e-12;
+        if (g.levels > 1)
+            multi_lane_search<KC>(g, g.all, x, y, z, x, y, z, PCR_INF, bs, 0.0, top, rowtab);
+        else
+            grid_search<KC>(g.v[0], g.all, x, y, z, x, y, z, PCR_INF, bs, 0.0, top);
+    }
     double c0 = x, c1 = y, c2 = z;
     int cnt = 0;
     bool open = true;  // prefix of the ascending list with d2 < MSD
@@ -35,7 +40,7 @@ __device__ __forceinline__ double sq_dist_to_centroid(const GridView &g, double 
         if (j < k) {
             open = open && top.idx[j] != PCR_NO_INDEX && top.d[j] < msd;
             if (open) {
-                const Pt4 p = g.pts[g.pos_of[top.idx[j]]];
+                const Pt4 p = g.all[g.pos_of[top.idx[j]]];
                 c0 += p.x;
                 c1 += p.y;
                 c2 += p.z;
@@ -51,32 +56,33 @@ __device__ __forceinline__ double sq_dist_to_centroid(const GridView &g, double 
 }
 
 template <int KC>
-__global__ void __launch_bounds__(256) reject_stat_kernel(GridView src, GridView tgt, const double *__restrict__ pp,
+__global__ void __launch_bounds__(256) reject_stat_kernel(MultiView src, MultiView tgt, const double *__restrict__ pp,
                                                           const double *__restrict__ pq, uint32_t P, int k,
                                                           double msd, double *__restrict__ d_out) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= P) return;
     double s[2];
+    __shared__ uint2 rowtab[9][256];  // per-lane row table of the ring walk (knn_device.h), nested indices only
     // one instance of the search code, run twice (target side first, as the reference does, :74-75)
 #pragma nounroll
     for (int side = 0; side < 2; ++side) {
-        const GridView &g = side ? src : tgt;
+        const MultiView &g = side ? src : tgt;
         const double *x = (side ? pp : pq) + (size_t)i * 3;
-        s[side] = sq_dist_to_centroid<KC>(g, x[0], x[1], x[2], k, msd);
+        s[side] = sq_dist_to_centroid<KC>(g, x[0], x[1], x[2], k, msd, &rowtab[0][threadIdx.x]);
     }
     d_out[i] = fabs(s[0] - s[1]);  // (:77)
 }
 
 // brute-force flavour for BRUTE indices: one lane per pair, plain global scan (small clouds only)
 template <int KC>
-__device__ __forceinline__ double sq_dist_to_centroid_brute(const GridView &g, double x, double y, double z, int k,
+__device__ __forceinline__ double sq_dist_to_centroid_brute(const MultiView &g, double x, double y, double z, int k,
                                                             double msd) {
     TopK<KC> top;
     top.init();
     double wd = PCR_INF;
     uint32_t wi = PCR_NO_INDEX;
     for (uint32_t j = 0; j < g.n; ++j) {
-        const Pt4 c = g.pts[j];
+        const Pt4 c = g.all[j];
         const double d = sqdist3(x, y, z, c.x, c.y, c.z);
         if (better(d, (uint32_t)c.w, wd, wi)) {
             top.insert(d, (uint32_t)c.w);
@@ -92,7 +98,7 @@ __device__ __forceinline__ double sq_dist_to_centroid_brute(const GridView &g, d
         if (j < k) {
             open = open && top.idx[j] != PCR_NO_INDEX && top.d[j] < msd;
             if (open) {
-                const Pt4 p = g.pts[g.pos_of[top.idx[j]]];
+                const Pt4 p = g.all[g.pos_of[top.idx[j]]];
                 c0 += p.x;
                 c1 += p.y;
                 c2 += p.z;
@@ -108,7 +114,7 @@ __device__ __forceinline__ double sq_dist_to_centroid_brute(const GridView &g, d
 }
 
 template <int KC>
-__global__ void __launch_bounds__(256) reject_stat_brute_kernel(GridView src, GridView tgt,
+__global__ void __launch_bounds__(256) reject_stat_brute_kernel(MultiView src, MultiView tgt,
                                                                 const double *__restrict__ pp,
                                                                 const double *__restrict__ pq, uint32_t P, int k,
                                                                 double msd, double *__restrict__ d_out) {

@@ -136,7 +136,18 @@ int pcr_sample_grid(pcr_ctx *ctx, const pcr_index *index, uint32_t cap, uint32_t
     PCR_REQUIRE(index->ctx == ctx, "pcr_sample_grid: index belongs to another context");
     PCR_REQUIRE(index->kind == PCR_INDEX_GRID, "pcr_sample_grid: needs a grid index");
     PCR_HIP(hipSetDevice(ctx->device));
-    return pick_compact(ctx, CellPick{index->cs_d, index->pts_d}, index->info.cells, cap, out_idx, out_count, true);
+    // every level of the index has cells of its own; the levels partition the cloud, so the picks are distinct
+    uint32_t total = 0;
+    for (int l = 0; l < index->view.levels; ++l) {
+        uint32_t got = 0;
+        int rc = pick_compact(ctx, CellPick{index->cs_d[l], index->view.v[l].pts}, index->cells[l], cap - total, out_idx + total,
+                              &got, false);
+        if (rc != PCR_OK) return rc;
+        total += got;
+    }
+    std::sort(out_idx, out_idx + total);
+    *out_count = total;
+    return PCR_OK;
 }
 
 }  // extern "C"

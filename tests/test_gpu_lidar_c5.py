@@ -18,6 +18,7 @@ def test_c5_2m_iteration_vs_oracle(pcr, ctx, oracle):
     n = 2_000_000
     src, tgt, Rm, t = synth.lidar_pair(n, 515)
     six, tix = pcr.Index(ctx, pcr.Cloud(ctx, src)), pcr.Index(ctx, pcr.Cloud(ctx, tgt))
+    assert six.info()["levels"] > 1 and tix.info()["levels"] > 1   # the dense core gets grids of its own
     U = tix.unique_sq_dist()
     assert U == _u(oracle, tgt)
     R, T = synth.colmajor(synth.euler_zyx(0.3, -0.2, 1.2)), np.array([0.3, -0.15, 0.04])  # a coarse guess
