@@ -235,14 +235,14 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "kernel": f"icp_step_grid_kernel<{k if k in (1, 4, 8, 16, 32) else '>=k'}>",
+                         "kernel": f"icp_step_grid_kernel<{k if k in (1, 4, 8, 16, 32) else '>=k'}, false>",
                          "kernel_ms_avg": step_ms, "launches": kt["step"][1],
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "other_kernels_ms_avg": {"transform": kt["transform"][0] / max(1, kt["transform"][1]),
                                                   "fold": kt["fold"][0] / max(1, kt["fold"][1])}},
             "knn_queries_per_s": knn,
             "index": {"build_ms_both_clouds": build_ms, "cell_size": info["cell_size"], "dims": info["dims"],
-                      "mean_occupancy": info["mean_occupancy"], "cells": info["cells"]},
+                      "mean_occupancy": info["mean_occupancy"], "cells": info["cells"], "levels": info["levels"]},
             "fit": {"kept_pairs_last": float(kept), "mse_last": float(mse), "max_abs_rot_err": rot_err,
                     "max_abs_trans_err": trans_err},
         }
