@@ -94,3 +94,61 @@ def test_grid_sampler_counts_every_level(pcr, ctx, scene):
     smp = pcr.sample_grid(ctx, nested[0])
     assert len(smp) == nested[0].info()["occupied_cells"]
     assert (np.diff(smp.astype(np.int64)) > 0).all() and smp.max() < len(src)
+
+
+def _skewed_clouds():
+    """Clouds built to stress the level split: (name, points)."""
+    rng = np.random.default_rng(11)
+    out = []
+    # a dense blob inside a sparse box, 60 % of the points exact duplicates of a handful of positions
+    bg = (rng.random((40000, 3)) - 0.5) * 100.0
+    blob = rng.standard_normal((60000, 3)) * 0.05 + [10.0, -5.0, 2.0]
+    dup = np.repeat(rng.standard_normal((6, 3)) * 0.02 + [10.0, -5.0, 2.0], 25000, axis=0)
+    out.append(("duplicates", np.concatenate([bg, blob, dup])))
+    # two far-apart dense clusters: their common box spans most of the cloud, so the build may not split at all
+    a = rng.standard_normal((50000, 3)) * 0.02 + [-40.0, -40.0, 0.0]
+    b = rng.standard_normal((50000, 3)) * 0.02 + [40.0, 40.0, 5.0]
+    out.append(("two_clusters", np.concatenate([bg, a, b])))
+    # everything in one plane (z == 0 exactly), density falling with the radius; and on one line
+    r = np.exp(rng.random(150000) * np.log(500.0)) * 0.1
+    th = rng.random(150000) * 2 * np.pi
+    out.append(("planar", np.stack([r * np.cos(th), r * np.sin(th), np.zeros_like(r)], 1)))
+    out.append(("collinear", np.stack([r * np.sign(np.cos(th)), np.zeros_like(r), np.zeros_like(r)], 1)))
+    # nested blobs: three scales inside each other (forces several levels)
+    out.append(("nested_blobs", np.concatenate([bg] + [rng.standard_normal((50000, 3)) * s + [1.0, 2.0, 3.0] for s in (5.0, 0.3, 0.01)])))
+    return out
+
+
+@pytest.mark.parametrize("case", range(5))
+def test_skewed_builds_answer_like_the_oracle(pcr, ctx, oracle, case):
+    name, pts = _skewed_clouds()[case]
+    pts = np.ascontiguousarray(pts)
+    cloud = pcr.Cloud(ctx, pts)
+    nested = pcr.Index(ctx, cloud, kind=pcr.INDEX_GRID)
+    two = pcr.Index(ctx, cloud, kind=pcr.INDEX_GRID, max_levels=2)
+    assert 1 <= two.info()["levels"] <= 2 and nested.info()["levels"] <= 6
+    rng = np.random.default_rng(case)
+    q = np.concatenate([pts[rng.choice(len(pts), 6000, replace=False)] + rng.standard_normal((6000, 3)) * 1e-3,
+                        pts[:500],
+                        (rng.random((500, 3)) - 0.5) * 400.0])
+    for k in (1, 5):
+        ia, da = nested.knn(q, k, want_d2=True)
+        ib, db = two.knn(q, k, want_d2=True)
+        assert (da == db).all(), name
+        wi, wd = oracle.KdOld(pts, k + 1).query(q, want_d2=True, threads=16)
+        assert (wd[:, :k] == da).all(), name
+        assert (ia == ib).all(), name
+        if name != "duplicates":
+            # an exact fp64 tie (it happens: far queries against a line of points) is decided by index here, by
+            # visiting order in the KD-tree (DESIGN 8.1); everywhere else the indices must agree
+            untied = (np.diff(wd, axis=1) > 0).all(1)
+            assert untied.mean() > 0.99 and (ia[untied] == wi[untied, :k]).all(), name
+        else:
+            # thousands of exact duplicates: check the lowest-index rule itself on a few queries by brute force,
+            # in the reference's operation order
+            for j in rng.choice(len(q), 60, replace=False):
+                d = ((q[j, 0] - pts[:, 0]) ** 2 + (q[j, 1] - pts[:, 1]) ** 2) + (q[j, 2] - pts[:, 2]) ** 2
+                best = np.lexsort((np.arange(len(pts)), d))[:k]
+                assert (best == ia[j]).all() and (d[best] == da[j]).all(), (name, j)
+    smp = pcr.sample_grid(ctx, nested)
+    assert len(smp) == nested.info()["occupied_cells"] and len(np.unique(smp)) == len(smp)
