@@ -76,7 +76,9 @@ int pcr_ctx_synchronize(pcr_ctx *ctx);
  * launch of the classes below is bracketed by a HIP event pair on the context's stream.
  * pcr_ctx_read_kernel_times synchronises, returns per class the summed kernel time in ms and the
  * number of launches since the previous read, and resets the counters.
- * class 0: source transform, 1: fused ICP step, 2: partial fold, 3: K-NN query. */
+ * class 0: source transform, 1: fused ICP step, 2: partial fold, 3: K-NN query.
+ * on: 0 = off, 1 = every class, otherwise (mask << 1) with bit c of mask selecting class c (an event pair costs
+ * a few microseconds of queue time per launch: a timed loop brackets only the kernel it reports). */
 int pcr_ctx_set_profiling(pcr_ctx *ctx, int on);
 int pcr_ctx_read_kernel_times(pcr_ctx *ctx, double sum_ms[4], uint32_t launches[4]);
 

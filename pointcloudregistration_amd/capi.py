@@ -152,8 +152,10 @@ class Context:
         if stream is not None:
             _check(lib().pcr_ctx_set_stream(self.h, _vp(stream.cuda_stream)), "pcr_ctx_set_stream")
 
-    def set_profiling(self, on):
-        _check(lib().pcr_ctx_set_profiling(self.h, 1 if on else 0), "pcr_ctx_set_profiling")
+    def set_profiling(self, on, classes=None):
+        """classes: iterable of kernel classes (0 transform, 1 step, 2 fold, 3 knn) to bracket; None = all."""
+        v = 0 if not on else (1 if classes is None else sum(1 << c for c in classes) << 1)
+        _check(lib().pcr_ctx_set_profiling(self.h, v), "pcr_ctx_set_profiling")
 
     def read_kernel_times(self):
         """{class: (sum_ms, launches)} since the previous read; synchronises the stream."""

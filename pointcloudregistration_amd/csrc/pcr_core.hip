@@ -652,6 +652,7 @@ int pcr_ctx_create(int device, pcr_ctx **out) {
     pcr_ctx *c = new pcr_ctx();
     c->device = device;
     c->profiling = false;
+    c->prof_mask = 0xfu;
     c->prof = nullptr;
     c->own_stream = true;
     c->stream = nullptr;
@@ -709,6 +710,7 @@ int pcr_ctx_set_profiling(pcr_ctx *c, int on) {
         memset(c->prof, 0, sizeof(pcr_prof));
     }
     c->profiling = on != 0;
+    c->prof_mask = on == 1 ? 0xfu : ((unsigned)on >> 1) & 0xfu;
     return PCR_OK;
 }
 

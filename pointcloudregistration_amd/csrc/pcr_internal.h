@@ -82,6 +82,7 @@ struct pcr_prof {
 struct pcr_ctx {
     int device;
     bool profiling;
+    unsigned prof_mask;  // bit c: launches of kernel class c are bracketed while profiling is on
     pcr_prof *prof;
     hipStream_t stream;
     bool own_stream;
@@ -103,7 +104,7 @@ struct ProfScope {
     pcr_ctx *c;
     int cls, slot;
     ProfScope(pcr_ctx *ctx, int k) : c(ctx), cls(k), slot(-1) {
-        if (!c->profiling || !c->prof) return;
+        if (!c->profiling || !c->prof || !((c->prof_mask >> cls) & 1u)) return;
         pcr_prof &p = *c->prof;
         if (p.used[cls] >= PCR_PROF_CAP) return;
         if (p.used[cls] >= p.created[cls]) {
