@@ -118,11 +118,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # PCR_BENCH_FORCE_DIST=1: run the collective path on a single rank too (rehearsal of the N > 1 code on one GPU)
     force_dist = os.environ.get("PCR_BENCH_FORCE_DIST") == "1"
+    # PCR_BENCH_REHEARSE_ONE_GPU=1: every rank on cuda:0 and gloo instead of RCCL (which refuses two ranks on one
+    # device) -- a rehearsal of the N > 1 code path on a one-GPU box; its numbers mean nothing
+    rehearse = os.environ.get("PCR_BENCH_REHEARSE_ONE_GPU") == "1"
+    if rehearse:
+        local_rank = 0
+        import faulthandler
+        faulthandler.dump_traceback_later(240, exit=True)  # a rehearsal that stalls says where
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node = --gpus"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -164,6 +174,8 @@ def main():
         for _ in range(steps):
             fit.step()
             if world > 1 or force_dist:
+                if rehearse:
+                    torch.cuda.synchronize()  # gloo stages through the host: tell a stalled kernel from a stalled exchange
                 dist.all_reduce(part_t)
             fit.solve()
 

@@ -1,0 +1,38 @@
+"""bench.py's N > 1 code path, rehearsed on the one GPU of the test box: two ranks launched exactly as the driver
+launches them (torch.distributed.run, one process per rank), both on cuda:0, partial sums exchanged through gloo
+(RCCL refuses two ranks on one device).  What is checked is the sharding and the exchange -- the sample ranges of the
+two ranks must add up to the single-rank fit -- not speed.  Collected last on purpose (a launcher test)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(extra_env, launcher, extra_args):
+    env = dict(os.environ, **extra_env)
+    cmd = [sys.executable] + launcher + [os.path.join(ROOT, "bench.py"), "--points", "200000", "--steps", "6", "--warmup", "1",
+                                         "--no-cpu-baseline", "--no-knn"] + extra_args
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout          # the contract: exactly one JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_bench_adds_up_to_the_single_rank_fit():
+    one = _bench({}, [], [])
+    two = _bench({"PCR_BENCH_REHEARSE_ONE_GPU": "1"},
+                 ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                  "--master-port", "29577"], ["--gpus", "2"])
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["steps"] == 6
+    assert two["fit"]["kept_pairs_last"] == one["fit"]["kept_pairs_last"] > 50000     # integer count: exact
+    assert abs(two["fit"]["mse_last"] - one["fit"]["mse_last"]) <= 1e-9 * one["fit"]["mse_last"]
+    assert abs(two["fit"]["max_abs_rot_err"] - one["fit"]["max_abs_rot_err"]) < 1e-9
+    for key in ("metric", "unit", "higher_is_better", "scaling", "dtype", "data"):
+        assert two[key] == one[key]
