@@ -56,9 +56,12 @@ const char *pcr_strerror(int status);
 const char *pcr_last_error(void);
 /* library version string; also names the target ISA it was compiled for */
 const char *pcr_version(void);
-/* Tuning knobs for experiments (no reference counterpart).  key 0: 0/1 = one lane per query, pruned ring walk (default), 2 = wave-staged LDS tile search;
- * 1 = one lane per query; key 1: unused; key 2: log2 of the brick edge used to order queries.
- * Results do not depend on them. */
+/* Tuning knobs for experiments (no reference counterpart).  Results do not depend on them.
+ *   key 2: log2 of the brick edge (in cells) used to order the samples of a step
+ *   key 3: 1 = leave K-NN query batches in the caller's order
+ *   key 4: how the ICP step gets at the transformed source for its reverse search: 0 = choose by cost (a
+ *          materialised copy when about every source point is a sample, else candidate by candidate while searching),
+ *          1 = always the copy, 2 = always on the fly */
 int pcr_tune(int key, int value);
 
 /* ---- context -----------------------------------------------------------------------

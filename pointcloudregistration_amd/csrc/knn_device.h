@@ -59,6 +59,20 @@ __device__ __forceinline__ void xform(const Rigid &M, double x, double y, double
     oz = dadd(dadd(dadd(dmul(M.r[2], x), dmul(M.r[5], y)), dmul(M.r[8], z)), M.t[2]);
 }
 
+// Squared distance from the query to a candidate record.  XF: the record holds the point in the index's own frame
+// and is moved by the current (R,T) first -- CPointCloud::transform's expression, so the value is the one the
+// reference gets from its transformed copy, without that copy ever being written or read.
+template <bool XF>
+__device__ __forceinline__ double cand_d2(const Rigid *xf, double qx, double qy, double qz, const Pt4 &c) {
+    if constexpr (XF) {
+        double x, y, z;
+        xform(*xf, c.x, c.y, c.z, x, y, z);
+        return sqdist3(qx, qy, qz, x, y, z);
+    } else {
+        return sqdist3(qx, qy, qz, c.x, c.y, c.z);
+    }
+}
+
 // (d, i) before (bd, bi) in the total order (d2, index).  Bitwise operators on purpose: no short-circuit
 // branches in the hot loops.
 __device__ __forceinline__ bool better(double d, uint32_t i, double bd, uint32_t bi) {
@@ -188,10 +202,11 @@ __device__ __forceinline__ double box_bound2(const GridView &g, double sx, doubl
 //   order: the grid-frame points the range is sorted by (g.pts); cand: what distances are evaluated against
 //   (g.pts again, or the transformed copy for the reverse search of the ICP step).
 #define PCR_LONG_RANGE 48u
-template <int KC>
+template <int KC, bool XF = false>
 __device__ __forceinline__ void windowed_scan(const Pt4 *__restrict__ order, const Pt4 *__restrict__ cand, uint32_t b,
                                               uint32_t e, double qx, double qy, double qz, double sx, double margin,
-                                              double bound_scale, TopK<KC> &top, double &wd, uint32_t &wi) {
+                                              double bound_scale, TopK<KC> &top, double &wd, uint32_t &wi,
+                                              const Rigid *xf = nullptr) {
     uint32_t lo = b, hi = e;
     while (lo < hi) {  // first position with x >= sx
         const uint32_t mid = lo + ((hi - lo) >> 1);
@@ -204,7 +219,7 @@ __device__ __forceinline__ void windowed_scan(const Pt4 *__restrict__ order, con
         const double gap = order[i].x - sx - margin;
         if ((gap > 0.0) & (gap * gap * bound_scale > wd)) break;
         const Pt4 c = cand[i];
-        const double d = sqdist3(qx, qy, qz, c.x, c.y, c.z);
+        const double d = cand_d2<XF>(xf, qx, qy, qz, c);
         const uint32_t ci = (uint32_t)c.w;
         if (better(d, ci, wd, wi)) {
             top.insert(d, ci);
@@ -217,7 +232,7 @@ __device__ __forceinline__ void windowed_scan(const Pt4 *__restrict__ order, con
         const double gap = sx - order[i].x - margin;
         if ((gap > 0.0) & (gap * gap * bound_scale > wd)) break;
         const Pt4 c = cand[i];
-        const double d = sqdist3(qx, qy, qz, c.x, c.y, c.z);
+        const double d = cand_d2<XF>(xf, qx, qy, qz, c);
         const uint32_t ci = (uint32_t)c.w;
         if (better(d, ci, wd, wi)) {
             top.insert(d, ci);
@@ -239,11 +254,11 @@ __device__ __forceinline__ void windowed_scan(const Pt4 *__restrict__ order, con
 //   max_d2   : candidates with d2 >= max_d2 are of no interest; the search may stop as soon as every
 //              unvisited point is at least that far
 // top must be initialised by the caller (init(), or pre-seeded with a known candidate).
-template <int KC, bool WINDOW = true>
+template <int KC, bool WINDOW = true, bool XF = false>
 __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__restrict__ cand, double qx, double qy,
                                             double qz, double sx, double sy, double sz, double max_d2,
                                             double bound_scale, double extra_margin, TopK<KC> &top,
-                                            int r_start = 1) {
+                                            int r_start = 1, const Rigid *xf = nullptr) {
     const uint32_t *__restrict__ cs = g.cs;
     const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
     const int cx = cell_coord(sx, g.lo[0], g.inv_h, gx);
@@ -344,7 +359,8 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
                             e = cs[base + xe + 1];
                             if constexpr (WINDOW) {
                                 if (e - p > PCR_LONG_RANGE && e > p) {  // dense stretch: enter at the query's x instead
-                                    windowed_scan<KC>(g.pts, cand, p, e, qx, qy, qz, sx, margin, bound_scale, top, wd, wi);
+                                    windowed_scan<KC, XF>(g.pts, cand, p, e, qx, qy, qz, sx, margin, bound_scale, top, wd, wi,
+                                                          xf);
                                     p = e;
                                 }
                             }
@@ -355,7 +371,7 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
             if (p >= e) break;
             DIAG_LANE_ADD(8 * (KC == 1) + 4, 1);  // candidates of the shell search
             const Pt4 c = cand[p];
-            const double d = sqdist3(qx, qy, qz, c.x, c.y, c.z);
+            const double d = cand_d2<XF>(xf, qx, qy, qz, c);
             const uint32_t ci = (uint32_t)c.w;
             if (better(d, ci, wd, wi)) {
                 top.insert(d, ci);
@@ -403,10 +419,11 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
 // rowtab: this lane's column, row r at rowtab[r * PCR_ROW_STRIDE] (consecutive lanes, 8 bytes: conflict-free).
 // Returns true if the K-th best is provably final (or the grid is exhausted).
 #define PCR_ROW_STRIDE 256
-template <int KC>
+template <int KC, bool XF = false>
 __device__ __forceinline__ bool ring1_pruned(const GridView &g, const Pt4 *__restrict__ cand, double qx, double qy,
                                              double qz, double sx, double sy, double sz, double max_d2,
-                                             double bound_scale, double extra_margin, TopK<KC> &top, uint2 *rowtab) {
+                                             double bound_scale, double extra_margin, TopK<KC> &top, uint2 *rowtab,
+                                             const Rigid *xf = nullptr) {
     const uint32_t *__restrict__ cs = g.cs;
     const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
     const int cx = cell_coord(sx, g.lo[0], g.inv_h, gx);
@@ -472,7 +489,7 @@ __device__ __forceinline__ bool ring1_pruned(const GridView &g, const Pt4 *__res
                 p = cs[xs];
                 e = cs[xe];
                 if (e - p > PCR_LONG_RANGE && e > p) {  // dense stretch: enter at the query's x instead
-                    windowed_scan<KC>(g.pts, cand, p, e, qx, qy, qz, sx, margin, bound_scale, top, wd, wi);
+                    windowed_scan<KC, XF>(g.pts, cand, p, e, qx, qy, qz, sx, margin, bound_scale, top, wd, wi, xf);
                     p = e;
                 }
             }
@@ -489,7 +506,7 @@ __device__ __forceinline__ bool ring1_pruned(const GridView &g, const Pt4 *__res
             DIAG_LANE_ADD(8 * (KC == 1) + 2, min(left, (uint32_t)PCR_WALK_UNROLL));
 #pragma unroll
             for (int u = 0; u < PCR_WALK_UNROLL; ++u) {
-                const double d = sqdist3(qx, qy, qz, c[u].x, c[u].y, c[u].z);
+                const double d = cand_d2<XF>(xf, qx, qy, qz, c[u]);
                 const uint32_t ci = (uint32_t)c[u].w;
                 if (((uint32_t)u < left) & better(d, ci, wd, wi)) {
                     top.insert(d, ci);
@@ -516,15 +533,15 @@ __device__ __forceinline__ bool ring1_pruned(const GridView &g, const Pt4 *__res
 }
 
 // The per-lane search the kernels use: pruned ring 1, then (rarely) the generic shells from ring 2 on.
-template <int KC>
+template <int KC, bool XF = false>
 __device__ __forceinline__ void lane_search(const GridView &g, const Pt4 *__restrict__ cand, double qx, double qy,
                                             double qz, double sx, double sy, double sz, double max_d2,
                                             double bound_scale, double extra_margin, TopK<KC> &top,
-                                            uint2 *rowtab) {
+                                            uint2 *rowtab, const Rigid *xf = nullptr) {
     DIAG_LANE_ADD(8 * (KC == 1) + 5, 1);  // lane searches
-    const bool fin1 = ring1_pruned<KC>(g, cand, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, rowtab);
+    const bool fin1 = ring1_pruned<KC, XF>(g, cand, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, rowtab, xf);
     if (!fin1)
-        grid_search<KC, false>(g, cand, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, 2);
+        grid_search<KC, false, XF>(g, cand, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, 2, xf);
 }
 
 // squared distance from the grid-frame query to a level's box of points, shrunk by the margin (0 inside)
@@ -577,10 +594,11 @@ __device__ __forceinline__ bool ring1_settles(const GridView &g, double sx, doub
 // then the others from coarse to fine -- the boxes are nested, so that is by increasing distance -- each skipped
 // once its whole box is provably farther than the current K-th best.  One call site per pass (2 x levels slots).
 // Exact: every level is searched exactly against the running top-K, and the levels partition the cloud.
-template <int KC>
+template <int KC, bool XF = false>
 __device__ __forceinline__ void multi_lane_search(const MultiView &M, const Pt4 *__restrict__ cand_all, double qx, double qy,
                                                   double qz, double sx, double sy, double sz, double max_d2,
-                                                  double bound_scale, double extra_margin, TopK<KC> &top, uint2 *rowtab) {
+                                                  double bound_scale, double extra_margin, TopK<KC> &top, uint2 *rowtab,
+                                                  const Rigid *xf = nullptr) {
     const int L = M.levels;
     const double qmargin = extra_margin + 9.094947017729282e-13 * (fabs(sx) + fabs(sy) + fabs(sz));
     uint32_t holds = 0, open = 0;
@@ -599,8 +617,8 @@ __device__ __forceinline__ void multi_lane_search(const MultiView &M, const Pt4 
         }
         if (go) {
             DIAG_LANE_ADD(8 * (KC == 1) + 5, 1);  // ring walks
-            const bool settled = ring1_pruned<KC>(g, cand_all + (g.pts - M.all), qx, qy, qz, sx, sy, sz, max_d2, bound_scale,
-                                                  extra_margin, top, rowtab);
+            const bool settled = ring1_pruned<KC, XF>(g, cand_all + (g.pts - M.all), qx, qy, qz, sx, sy, sz, max_d2,
+                                                      bound_scale, extra_margin, top, rowtab, xf);
             open |= settled ? 0u : 1u << l;
         }
     }
@@ -615,8 +633,8 @@ __device__ __forceinline__ void multi_lane_search(const MultiView &M, const Pt4 
                      !ring1_settles(g, sx, sy, sz, g.margin + qmargin, bound_scale, top.worst_d(), max_d2);
             }
             if (go)
-                grid_search<KC, true>(g, cand_all + (g.pts - M.all), qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top,
-                                      2);
+                grid_search<KC, true, XF>(g, cand_all + (g.pts - M.all), qx, qy, qz, sx, sy, sz, max_d2, bound_scale,
+                                          extra_margin, top, 2, xf);
         }
 }
 

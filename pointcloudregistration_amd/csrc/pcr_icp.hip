@@ -136,7 +136,10 @@ __device__ __forceinline__ void accumulate(double (&acc)[17], bool keep, double 
 
 // MULTI: either index has more than one level (clouds of very uneven density); the single-level instance is the
 // plain search on level 0, with none of the level loop in its code.
-template <int KC, bool MULTI>
+// XF: the reverse search moves its candidates by (R,T) as it reads them (from the source index itself) instead of
+// reading a transformed copy of the source: no transform_kernel launch, no 64 B/point of HBM traffic per iteration
+// and -- what matters on several GPUs -- no per-rank work proportional to the WHOLE source.
+template <int KC, bool MULTI, bool XF>
 __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(StepArgs A) {
     const StepDyn *__restrict__ dynp = A.dyn;
     if (dynp->done) return;  // uniform over the grid
@@ -202,20 +205,27 @@ __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(Step
     rt.idx[0] = orig;
     const bool rev_active = need_rev && isfinite(sx) && isfinite(sy) && isfinite(sz);
     if (rev_active) {
+        const Pt4 *rcand = XF ? A.src.all : A.tsrc;
         if constexpr (MULTI)
-            multi_lane_search<1>(A.src, A.tsrc, qx, qy, qz, sx, sy, sz, PCR_INF, D.rev_bound_scale, D.rev_extra_margin, rt,
-                                 my_rows);
+            multi_lane_search<1, XF>(A.src, rcand, qx, qy, qz, sx, sy, sz, PCR_INF, D.rev_bound_scale, D.rev_extra_margin, rt,
+                                     my_rows, &D.M);
         else
-            lane_search<1>(A.src.v[0], A.tsrc, qx, qy, qz, sx, sy, sz, PCR_INF, D.rev_bound_scale, D.rev_extra_margin, rt,
-                           my_rows);
+            lane_search<1, XF>(A.src.v[0], rcand, qx, qy, qz, sx, sy, sz, PCR_INF, D.rev_bound_scale, D.rev_extra_margin, rt,
+                               my_rows, &D.M);
     }
     uint32_t r = PCR_NO_INDEX;
     bool keep = false;
     if (need_rev) {
         r = rt.idx[0];
-        const Pt4 pp = A.tsrc[r == orig ? pos : A.src_pos_of[r]];
-        const double dR = sqdist3(px, py, pz, pp.x, pp.y, pp.z);  // (CurSrcPoint - TmpPoint).squaredNorm()
-        keep = passF && dR < A.thr_rev;                           // strict < (:98)
+        double dR;  // (CurSrcPoint - TmpPoint).squaredNorm()
+        if constexpr (XF) {
+            const Pt4 sp = A.src.all[r == orig ? pos : A.src_pos_of[r]];
+            dR = cand_d2<true>(&D.M, px, py, pz, sp);
+        } else {
+            const Pt4 pp = A.tsrc[r == orig ? pos : A.src_pos_of[r]];
+            dR = sqdist3(px, py, pz, pp.x, pp.y, pp.z);
+        }
+        keep = passF && dR < A.thr_rev;  // strict < (:98)
     }
     if (live) {
         accumulate(acc, keep, px, py, pz, qx, qy, qz, dF, D);
@@ -478,17 +488,30 @@ struct pcr_fit {
 
 static void launch_step_kernels(pcr_ctx *ctx, const pcr_index *src, const StepArgs &A, uint32_t nb, uint32_t k,
                                 double *partials_d) {
-    {  // CPointCloud::transform of the whole source (:73-74), in index order
+    // CPointCloud::transform of the whole source (:73-74): the grid kernels do it candidate by candidate as they
+    // search; a materialised copy (in index order) is only made for the brute-force kernel, or on request (tune 4)
+    // Which is cheaper depends on how many samples this launch serves: the copy costs ~11 us per million SOURCE points
+    // plus a launch, moving candidates on the fly ~24 us per million SAMPLES (measured, 1 M x 1 M, K=4).  A rank of a
+    // sharded fit, or a sampled fit, searches on the fly; a single GPU running every point as a sample copies.
+    // tune 4: 0 = by this rule, 1 = always copy, 2 = always on the fly.
+    const bool on_the_fly = src->kind == PCR_INDEX_GRID &&
+                            (g_tune[4] == 2 || (g_tune[4] == 0 && 24.0 * (double)A.m < 11.2 * (double)src->n + 6.0e6));
+    if (!on_the_fly) {
         ProfScope ps(ctx, PCR_PROF_TRANSFORM);
         hipLaunchKernelGGL(transform_kernel, dim3(min(2048u, (src->n + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const Pt4 *)src->pts_d, src->n, A.dyn, src->tpts_d);
     }
 #define LAUNCH_STEP(KC)                                                                                \
     do {                                                                                               \
-        if (src->kind == PCR_INDEX_GRID && (A.src.levels > 1 || A.tgt.levels > 1))                    \
-            hipLaunchKernelGGL((icp_step_grid_kernel<KC, true>), dim3(nb), dim3(256), 0, ctx->stream, A); \
+        const bool multi__ = A.src.levels > 1 || A.tgt.levels > 1;                                     \
+        if (src->kind == PCR_INDEX_GRID && multi__ && on_the_fly)                                      \
+            hipLaunchKernelGGL((icp_step_grid_kernel<KC, true, true>), dim3(nb), dim3(256), 0, ctx->stream, A);  \
+        else if (src->kind == PCR_INDEX_GRID && multi__)                                               \
+            hipLaunchKernelGGL((icp_step_grid_kernel<KC, true, false>), dim3(nb), dim3(256), 0, ctx->stream, A); \
+        else if (src->kind == PCR_INDEX_GRID && on_the_fly)                                            \
+            hipLaunchKernelGGL((icp_step_grid_kernel<KC, false, true>), dim3(nb), dim3(256), 0, ctx->stream, A); \
         else if (src->kind == PCR_INDEX_GRID)                                                          \
-            hipLaunchKernelGGL((icp_step_grid_kernel<KC, false>), dim3(nb), dim3(256), 0, ctx->stream, A); \
+            hipLaunchKernelGGL((icp_step_grid_kernel<KC, false, false>), dim3(nb), dim3(256), 0, ctx->stream, A); \
         else                                                                                           \
             hipLaunchKernelGGL(icp_step_brute_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, A);     \
     } while (0)
