@@ -160,6 +160,9 @@ def main():
     thr_f, thr_r = U * sdft, U * ndft
 
     begin, m = shard_range(n, rank, world)
+    emulate = int(os.environ.get("PCR_BENCH_EMULATE_SHARDS", "0"))  # debug: one rank does the share of 1/N (no peers)
+    if emulate > 1:
+        begin, m = shard_range(n, 0, emulate)
     R0, T0 = synth.coarse_initial_transform(R_true, t_true, n)
 
     # The device-resident loop (pcr_fit_*): per iteration the host only ENQUEUES transform + fused step + fold,

@@ -54,7 +54,9 @@ PCR_HD inline void svd3_hestenes(const double *H, double *U, double *S, double *
                     beta += el(A, r, j) * el(A, r, j);
                     gamma += el(A, r, i) * el(A, r, j);
                 }
-                if (fabs(gamma) <= 1e-17 * sqrt(alpha * beta) || gamma == 0.0) continue;
+                // orthogonal to within two units of roundoff: a stricter test is not reachable in general (gamma
+                // then hovers at rounding noise and the sweeps run to the limit -- 50+ us on one device thread)
+                if (fabs(gamma) <= 4.440892098500626e-16 * sqrt(alpha * beta)) continue;
                 rotated = true;
                 const double zeta = (beta - alpha) / (2.0 * gamma);
                 const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
