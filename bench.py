@@ -254,7 +254,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "kernel": f"icp_step_grid_kernel<{k if k in (1, 4, 8, 16, 32) else '>=k'}, false>",
+                         "kernel": f"icp_step_grid_kernel<{k if k in (1, 4, 8, 16, 32) else '>=k'}, false, {'false' if world == 1 else 'true'}>",
                          "kernel_ms_avg": step_ms, "launches": kt["step"][1],
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "other_kernels_ms_avg": {"transform": kt_warm["transform"][0] / max(1, kt_warm["transform"][1]),
