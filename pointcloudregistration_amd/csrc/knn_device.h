@@ -453,6 +453,19 @@ __device__ __forceinline__ bool ring1_pruned(const GridView &g, const Pt4 *__res
     gh = gh > 0.0 ? gh : 0.0;
     const double fzl = gl, fzh = gh;
     const double gzl = gl * gl * bound_scale, gzh = gh * gh * bound_scale;
+    // When will the K-th best be final?  An unvisited point is either in a pruned row/cell (farther than the bound
+    // that pruned it, which was >= the final wd) or outside the 3x3x3 box, i.e. beyond a box face: at least one whole
+    // cell plus the (margin-shrunk, clamped) gap to the own cell's face away along that axis.  Faces on the grid
+    // boundary have nothing beyond them.  Geometry only -- computed here, before the walk, so that one value
+    // instead of six gaps stays live across the loop.
+    double settle_b2 = PCR_INF;
+    if (cx > 1) settle_b2 = fmin(settle_b2, (fxl + g.h) * (fxl + g.h));
+    if (cx < gx - 2) settle_b2 = fmin(settle_b2, (fxh + g.h) * (fxh + g.h));
+    if (cy > 1) settle_b2 = fmin(settle_b2, (fyl + g.h) * (fyl + g.h));
+    if (cy < gy - 2) settle_b2 = fmin(settle_b2, (fyh + g.h) * (fyh + g.h));
+    if (cz > 1) settle_b2 = fmin(settle_b2, (fzl + g.h) * (fzl + g.h));
+    if (cz < gz - 2) settle_b2 = fmin(settle_b2, (fzh + g.h) * (fzh + g.h));
+    settle_b2 *= bound_scale * (1.0 - 4.440892098500626e-16);
     // row table, rows in order of increasing slab distance class: centre, 4 faces, 4 edges.  The slab distance is
     // kept as a float rounded DOWN (a smaller bound only prunes less); rows outside the grid get +inf = never open.
     // The cell table has <= 2^30 entries (pcr_index_params.max_cells), so its offsets fit 32 bits.
@@ -517,19 +530,7 @@ __device__ __forceinline__ bool ring1_pruned(const GridView &g, const Pt4 *__res
         }
         alive = (p < e) | (ri < 9);
     }
-    // Is the K-th best final?  An unvisited point is either in a pruned row/cell (farther than the bound that
-    // pruned it, which was >= the final wd) or outside the 3x3x3 box, i.e. beyond a box face: at least one whole
-    // cell plus the (margin-shrunk, clamped) gap to the own cell's face away along that axis.  Faces on the grid
-    // boundary have nothing beyond them.
-    double b2 = PCR_INF;
-    if (cx > 1) b2 = fmin(b2, (fxl + g.h) * (fxl + g.h));
-    if (cx < gx - 2) b2 = fmin(b2, (fxh + g.h) * (fxh + g.h));
-    if (cy > 1) b2 = fmin(b2, (fyl + g.h) * (fyl + g.h));
-    if (cy < gy - 2) b2 = fmin(b2, (fyh + g.h) * (fyh + g.h));
-    if (cz > 1) b2 = fmin(b2, (fzl + g.h) * (fzl + g.h));
-    if (cz < gz - 2) b2 = fmin(b2, (fzh + g.h) * (fzh + g.h));
-    b2 *= bound_scale * (1.0 - 4.440892098500626e-16);
-    return (wd < b2) | (max_d2 <= b2);
+    return (wd < settle_b2) | (max_d2 <= settle_b2);
 }
 
 // The per-lane search the kernels use: pruned ring 1, then (rarely) the generic shells from ring 2 on.
