@@ -303,7 +303,7 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
         // is a float square root rounded up).  A query hovering above a dense surface thus opens the few rows below
         // it, not the whole box. ----
         int rz = z0 - 1, ry = 0, ylast = -1, seg = 0;
-        double rem_z = 0.0;
+        double rem_z = 0.0, dz2 = 0.0;
         uint32_t p = 0, e = 0;
         for (;;) {
             bool exhausted = false;
@@ -317,7 +317,8 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
                         }
                         const double reach = fmin(wd, max_d2) * inv_bs;
                         const double dz = slab_gap(sz, g.lo[2], rz, g.h, margin);
-                        rem_z = reach - dz * dz;
+                        dz2 = dz * dz;
+                        rem_z = reach - dz2;
                         if (!(rem_z >= 0.0)) continue;  // the whole layer is out of reach
                         const double w = ball_half_width(rem_z) + margin;
                         double lo_c = (sy - w - g.lo[1]) * g.inv_h - 1.0, hi_c = (sy + w - g.lo[1]) * g.inv_h + 1.0;
@@ -344,7 +345,7 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
                 }
                 if (xs <= xe) {
                     const double dy = slab_gap(sy, g.lo[1], ry, g.h, margin);
-                    const double rem = rem_z - dy * dy;
+                    const double rem = fmin(wd, max_d2) * inv_bs - dz2 - dy * dy;  // with the K-th distance of NOW
                     if (rem >= 0.0) {
                         const double w = ball_half_width(rem) + margin;
                         double lo_c = (sx - w - g.lo[0]) * g.inv_h - 1.0, hi_c = (sx + w - g.lo[0]) * g.inv_h + 1.0;

@@ -63,13 +63,11 @@ __global__ void __launch_bounds__(256) reject_stat_kernel(MultiView src, MultiVi
     if (i >= P) return;
     double s[2];
     __shared__ uint2 rowtab[9][256];  // per-lane row table of the ring walk (knn_device.h), nested indices only
-    // one instance of the search code, run twice (target side first, as the reference does, :74-75)
-#pragma nounroll
-    for (int side = 0; side < 2; ++side) {
-        const MultiView &g = side ? src : tgt;
-        const double *x = (side ? pp : pq) + (size_t)i * 3;
-        s[side] = sq_dist_to_centroid<KC>(g, x[0], x[1], x[2], k, msd, &rowtab[0][threadIdx.x]);
-    }
+    // target side first, as the reference does (:74-75).  Two call sites on purpose: a run-time choice between the
+    // two index arguments would make the compiler copy both (1.4 KB) into every lane's scratch memory.
+    uint2 *my_rows = &rowtab[0][threadIdx.x];
+    s[0] = sq_dist_to_centroid<KC>(tgt, pq[(size_t)i * 3], pq[(size_t)i * 3 + 1], pq[(size_t)i * 3 + 2], k, msd, my_rows);
+    s[1] = sq_dist_to_centroid<KC>(src, pp[(size_t)i * 3], pp[(size_t)i * 3 + 1], pp[(size_t)i * 3 + 2], k, msd, my_rows);
     d_out[i] = fabs(s[0] - s[1]);  // (:77)
 }
 
