@@ -13,7 +13,7 @@
 namespace pcr {
 
 static thread_local char g_last_error[512] = "";
-int g_tune[8] = {0, 1, 0, 0, 0, 0, 0, 0};  // [0] 0/1: per-lane search (default), 2: LDS tile search
+int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // pcr_tune keys, see include/pcr.h (2: brick edge, 3: query order, 4: reverse-search copy)
 
 void set_last_error(const char *fmt, ...) {
     va_list ap;

@@ -9,7 +9,7 @@
 
 namespace pcr {
 
-// tuning knobs (pcr_tune): 0 search mode (0 wave-cooperative, 1 per-lane), 1 initial halo of the wave box
+// tuning knobs (pcr_tune, include/pcr.h)
 extern int g_tune[8];
 
 void set_last_error(const char *fmt, ...);
