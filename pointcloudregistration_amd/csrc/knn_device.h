@@ -297,89 +297,103 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
         const int x0 = max(cx - r, 0), x1 = min(cx + r, gx - 1);
         const int y0 = max(cy - r, 0), y1 = min(cy + r, gy - 1);
         const int z0 = max(cz - r, 0), z1 = min(cz + r, gz - 1);
-        // ---- flattened scan of the shell: one candidate per trip, rows advanced on demand.  Of the box only the
-        // part inside the BALL of everything that can still matter is enumerated: a layer's rows are limited to
-        // the disc the ball cuts out of it, a row's cells to the chord (one cell of slack either side; the radius
-        // is a float square root rounded up).  A query hovering above a dense surface thus opens the few rows below
-        // it, not the whole box. ----
-        int rz = z0 - 1, ry = 0, ylast = -1, seg = 0;
-        double rem_z = 0.0, dz2 = 0.0;
+        // ---- scan of the shell, flattened into ONE loop: every trip a lane does one unit of work -- evaluates a
+        // candidate, or moves to the next layer, or handles the next row (segment) -- so a wave runs as long as its
+        // busiest lane, not as long as all its lanes' empty rows added up (an inner loop "until a row has
+        // candidates" would make every lane wait for every other lane's search for one).  Of the box only the part
+        // inside the BALL of everything that can still matter is looked at: a layer's rows are limited to the disc
+        // the ball cuts out of it, a row's cells to the chord (one cell of slack either side; the radius is a float
+        // square root rounded up), and a row is pruned with the K-th distance of the moment.  A query hovering
+        // above a dense surface thus opens the few rows below it, not the whole box. ----
+        int rz = z0 - 1, ry = 0, ylast = -1, seg = 0;  // ry > ylast: the layer is used up
+        bool layer_start = false, alive = true;
+        double dz2 = 0.0;
         uint32_t p = 0, e = 0;
-        for (;;) {
-            bool exhausted = false;
-            while (p >= e) {
-                if (seg == 0) {  // next row; next layer when the current one has no rows left
-                    ++ry;
-                    while (ry > ylast) {
-                        if (++rz > z1) {
-                            exhausted = true;
-                            break;
-                        }
-                        const double reach = fmin(wd, max_d2) * inv_bs;
-                        const double dz = slab_gap(sz, g.lo[2], rz, g.h, margin);
-                        dz2 = dz * dz;
-                        rem_z = reach - dz2;
-                        if (!(rem_z >= 0.0)) continue;  // the whole layer is out of reach
+        while (alive) {
+            if (p < e) {
+                DIAG_LANE_ADD(8 * (KC == 1) + 4, 1);  // candidates of the shell search
+                const Pt4 c = cand[p];
+                const double d = cand_d2<XF>(xf, qx, qy, qz, c);
+                const uint32_t ci = (uint32_t)c.w;
+                if (better(d, ci, wd, wi)) {
+                    top.insert(d, ci);
+                    wd = top.worst_d();
+                    wi = top.worst_i();
+                }
+                ++p;
+            } else if (ry > ylast) {  // the next layer
+                if (++rz > z1) {
+                    alive = false;
+                } else {
+                    const double dz = slab_gap(sz, g.lo[2], rz, g.h, margin);
+                    dz2 = dz * dz;
+                    const double rem_z = fmin(wd, max_d2) * inv_bs - dz2;
+                    if (rem_z >= 0.0) {  // else the whole layer is out of reach: ry > ylast stays, the next trip moves on
                         const double w = ball_half_width(rem_z) + margin;
                         double lo_c = (sy - w - g.lo[1]) * g.inv_h - 1.0, hi_c = (sy + w - g.lo[1]) * g.inv_h + 1.0;
                         lo_c = fmin(fmax(lo_c, (double)y0), (double)y1 + 1.0);
                         hi_c = fmax(fmin(hi_c, (double)y1), (double)y0 - 1.0);
                         ry = (int)lo_c;
                         ylast = (int)hi_c;
+                        layer_start = true;
                     }
-                    if (exhausted) break;
                 }
-                const bool inner = (ry >= py0) & (ry <= py1) & (rz >= pz0) & (rz <= pz1);
-                int xs, xe;
-                if (!inner) {
-                    xs = x0;
-                    xe = x1;
-                } else if (seg == 0) {
-                    xs = x0;
-                    xe = px0 - 1;
-                    seg = 1;
+            } else {  // row ry of layer rz (its next segment)
+                bool skip = false;
+                if constexpr (WINDOW) {
+                    // entering a strip of 8x8 rows (or the layer, in the middle of one): if the strip holds no point
+                    // at all in the shell's x-range, its rows of this layer are skipped with two loads
+                    if ((seg == 0) & (((ry & 7) == 0) | layer_start) && g.cs8) {
+                        const size_t b8 = ((size_t)(rz >> 3) * g.gy8 + (ry >> 3)) * gx;
+                        skip = g.cs8[b8 + x1 + 1] == g.cs8[b8 + x0];
+                    }
+                }
+                layer_start = false;
+                if (skip) {
+                    ry = (ry | 7) + 1;
                 } else {
-                    xs = px1 + 1;
-                    xe = x1;
-                    seg = 0;
-                }
-                if (xs <= xe) {
-                    const double dy = slab_gap(sy, g.lo[1], ry, g.h, margin);
-                    const double rem = fmin(wd, max_d2) * inv_bs - dz2 - dy * dy;  // with the K-th distance of NOW
-                    if (rem >= 0.0) {
-                        const double w = ball_half_width(rem) + margin;
-                        double lo_c = (sx - w - g.lo[0]) * g.inv_h - 1.0, hi_c = (sx + w - g.lo[0]) * g.inv_h + 1.0;
-                        lo_c = fmin(fmax(lo_c, (double)xs), (double)xe + 1.0);
-                        hi_c = fmax(fmin(hi_c, (double)xe), (double)xs - 1.0);
-                        xs = (int)lo_c;
-                        xe = (int)hi_c;
-                        if (xs <= xe) {
-                            DIAG_LANE_ADD(8 * (KC == 1) + 3, 1);  // rows opened by the shell search
-                            const size_t base = ((size_t)rz * gy + ry) * gx;
-                            p = cs[base + xs];
-                            e = cs[base + xe + 1];
-                            if constexpr (WINDOW) {
-                                if (e - p > PCR_LONG_RANGE && e > p) {  // dense stretch: enter at the query's x instead
-                                    windowed_scan<KC, XF>(g.pts, cand, p, e, qx, qy, qz, sx, margin, bound_scale, top, wd, wi,
-                                                          xf);
-                                    p = e;
+                    const bool inner = (ry >= py0) & (ry <= py1) & (rz >= pz0) & (rz <= pz1);
+                    int xs, xe;
+                    if (!inner) {
+                        xs = x0;
+                        xe = x1;
+                    } else if (seg == 0) {
+                        xs = x0;
+                        xe = px0 - 1;
+                        seg = 1;
+                    } else {
+                        xs = px1 + 1;
+                        xe = x1;
+                        seg = 0;
+                    }
+                    if (xs <= xe) {
+                        const double dy = slab_gap(sy, g.lo[1], ry, g.h, margin);
+                        const double rem = fmin(wd, max_d2) * inv_bs - dz2 - dy * dy;  // with the K-th distance of NOW
+                        if (rem >= 0.0) {
+                            const double w = ball_half_width(rem) + margin;
+                            double lo_c = (sx - w - g.lo[0]) * g.inv_h - 1.0, hi_c = (sx + w - g.lo[0]) * g.inv_h + 1.0;
+                            lo_c = fmin(fmax(lo_c, (double)xs), (double)xe + 1.0);
+                            hi_c = fmax(fmin(hi_c, (double)xe), (double)xs - 1.0);
+                            xs = (int)lo_c;
+                            xe = (int)hi_c;
+                            if (xs <= xe) {
+                                DIAG_LANE_ADD(8 * (KC == 1) + 3, 1);  // rows opened by the shell search
+                                const size_t base = ((size_t)rz * gy + ry) * gx;
+                                p = cs[base + xs];
+                                e = cs[base + xe + 1];
+                                if constexpr (WINDOW) {
+                                    if (e - p > PCR_LONG_RANGE && e > p) {  // dense stretch: enter at the query's x instead
+                                        windowed_scan<KC, XF>(g.pts, cand, p, e, qx, qy, qz, sx, margin, bound_scale, top, wd,
+                                                              wi, xf);
+                                        p = e;
+                                    }
                                 }
                             }
                         }
                     }
+                    if (seg == 0) ++ry;  // the row's last segment has been handled
                 }
             }
-            if (p >= e) break;
-            DIAG_LANE_ADD(8 * (KC == 1) + 4, 1);  // candidates of the shell search
-            const Pt4 c = cand[p];
-            const double d = cand_d2<XF>(xf, qx, qy, qz, c);
-            const uint32_t ci = (uint32_t)c.w;
-            if (better(d, ci, wd, wi)) {
-                top.insert(d, ci);
-                wd = top.worst_d();
-                wi = top.worst_i();
-            }
-            ++p;
         }
         // ---- can anything outside the scanned box still matter? ----
         const bool all = (x0 == 0) & (x1 == gx - 1) & (y0 == 0) & (y1 == gy - 1) & (z0 == 0) & (z1 == gz - 1);

@@ -231,6 +231,30 @@ __global__ void __launch_bounds__(256) pack_kernel(const double *__restrict__ xy
     }
 }
 
+// ------------------------------------------------------------------ strip table
+// Points per strip cell: a strip is 8x8 (y,z) rows of cells, x stays at full resolution (GridView::cs8).  One thread
+// per strip cell; consecutive threads are consecutive x, so every one of the 64 reads is coalesced.
+__global__ void __launch_bounds__(256) strip_count_kernel(const uint32_t *__restrict__ cs, int gx, int gy, int gz, int gy8,
+                                                          uint64_t strips, uint32_t *__restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= strips) return;
+    const int x = (int)(t % (uint64_t)gx);
+    const uint64_t s = t / (uint64_t)gx;
+    const int y8 = (int)(s % (uint64_t)gy8), z8 = (int)(s / (uint64_t)gy8);
+    uint32_t c = 0;
+    for (int dz = 0; dz < 8; ++dz) {
+        const int z = z8 * 8 + dz;
+        if (z >= gz) break;
+        for (int dy = 0; dy < 8; ++dy) {
+            const int y = y8 * 8 + dy;
+            if (y >= gy) break;
+            const size_t cell = ((size_t)z * gy + y) * gx + x;
+            c += cs[cell + 1] - cs[cell];
+        }
+    }
+    out[t] = c;
+}
+
 // ------------------------------------------------------------------ nested levels (uneven density)
 // Where are the cells that hold too many points?  For two thresholds thr[0] <= thr[1], over the cells with more
 // than thr[t] points: their total mass and the box of their cell coordinates.
@@ -832,8 +856,10 @@ int pcr_index_free(pcr_index *ix) {
     hipSetDevice(ix->ctx->device);
     if (ix->pts_d) hipFree(ix->pts_d);
     if (ix->tpts_d) hipFree(ix->tpts_d);
-    for (int l = 0; l < PCR_MAX_LEVELS; ++l)
+    for (int l = 0; l < PCR_MAX_LEVELS; ++l) {
         if (ix->cs_d[l]) hipFree(ix->cs_d[l]);
+        if (ix->cs8_d[l]) hipFree(ix->cs8_d[l]);
+    }
     if (ix->pos_of_d) hipFree(ix->pos_of_d);
     if (ix->order_d) hipFree(ix->order_d);
     delete ix;
@@ -1084,6 +1110,8 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
             V.n = n;
             V.pts = ix->pts_d;
             V.cs = nullptr;
+            V.cs8 = nullptr;
+            V.gy8 = 1;
             V.h = V.inv_h = 1.0;
             V.g[0] = V.g[1] = V.g[2] = 1;
             hipLaunchKernelGGL(pack_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, cloud->xyz_d, n,
@@ -1167,7 +1195,29 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
                 hipFree(cursor_d);
                 cursor_d = nullptr;
             }
+            // ---- strip table of the level (lets the shell search skip 8x8 blocks of empty rows) ----
+            const int gy8 = (B.G.g[1] + 7) / 8, gz8 = (B.G.g[2] + 7) / 8;
+            const uint64_t strips = (uint64_t)B.G.g[0] * gy8 * gz8;
+            {
+                const uint32_t tiles8 = (uint32_t)((strips + SCAN_TILE - 1) / SCAN_TILE);
+                uint32_t *tiles8_d = nullptr;
+                BUILD_HIP(hipMalloc(&ix->cs8_d[l], sizeof(uint32_t) * (strips + 1)));
+                BUILD_HIP(hipMalloc(&tiles8_d, sizeof(uint32_t) * (tiles8 + 1)));
+                hipLaunchKernelGGL(strip_count_kernel, dim3((unsigned)((strips + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   (const uint32_t *)B.counts_d, B.G.g[0], B.G.g[1], B.G.g[2], gy8, strips, ix->cs8_d[l]);
+                hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(tiles8), dim3(256), 0, ctx->stream,
+                                   (const uint32_t *)ix->cs8_d[l], strips, tiles8_d, stats_d);
+                hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, tiles8_d, tiles8);
+                hipLaunchKernelGGL(scan_apply_kernel, dim3(tiles8), dim3(256), 0, ctx->stream, ix->cs8_d[l], strips,
+                                   (const uint32_t *)tiles8_d, n_l);
+                hipError_t e8 = hipStreamSynchronize(ctx->stream);
+                hipFree(tiles8_d);
+                BUILD_HIP(e8);
+                BUILD_HIP(hipGetLastError());
+            }
             GridView &V = M.v[l];
+            V.cs8 = ix->cs8_d[l];
+            V.gy8 = gy8;
             for (int a = 0; a < 3; ++a) {
                 V.lo[a] = lo[a];
                 V.hi[a] = hi[a];
@@ -1210,7 +1260,7 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
         ix->info.mean_occupancy = (double)n / (double)(occupied_total ? occupied_total : 1);
         ix->info.max_occupancy = max_occ;
         ix->info.levels = (uint32_t)M.levels;
-        ix->info.device_bytes = (sizeof(Pt4) * 2 + 8) * (uint64_t)n + 4 * (cells_total + M.levels);
+        ix->info.device_bytes = (sizeof(Pt4) * 2 + 8) * (uint64_t)n + 4 * (cells_total + M.levels) + cells_total / 8;
     }
     release(B);
     if (stats_d) hipFree(stats_d);

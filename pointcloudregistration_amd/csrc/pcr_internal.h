@@ -43,6 +43,10 @@ struct __attribute__((aligned(32))) Pt4 {
 struct GridView {
     const Pt4 *pts;       // [n] in cell order (GRID) or in original order (BRUTE)
     const uint32_t *cs;   // [cells+1] exclusive cell starts; NULL for BRUTE
+    const uint32_t *cs8;  // [g[0]*gy8*gz8 + 1] the same for STRIPS of 8x8 (y,z) rows, x at full resolution: the
+                          // points of cells x0..x1 of a strip number cs8[b+x1+1] - cs8[b+x0] -- zero lets a search
+                          // skip 64 rows with two loads.  NULL for BRUTE
+    int gy8;              // strips along y = ceil(g[1] / 8)
     double lo[3], hi[3];  // bounds of the points
     double h, inv_h;      // cell edge
     double margin;        // absolute safety margin on face distances, ~2^-40 * coordinate scale
@@ -157,5 +161,6 @@ struct pcr_index {
     pcr::MultiView view;
     uint32_t *cs_d[pcr::PCR_MAX_LEVELS];    // [cells+1] of every level, positions relative to the level's segment
     uint64_t cells[pcr::PCR_MAX_LEVELS];
+    uint32_t *cs8_d[pcr::PCR_MAX_LEVELS];   // strip tables (GridView::cs8)
     pcr_index_info info;
 };
