@@ -17,7 +17,7 @@ namespace pcr {
 
 #ifdef PCR_DIAG
 // diagnostic build only (libpcr_diag.so): counters of the lane search.  Never compiled into libpcr.so.
-static __device__ unsigned long long g_diag[16];
+static __device__ unsigned long long g_diag[32];
 #define DIAG_T() ((unsigned long long)__builtin_amdgcn_s_memtime())
 #define DIAG_ADD(slot, v)                                                                \
     do {                                                                                 \
@@ -292,8 +292,18 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
     const int rmax = max(max(gx, gy), gz);
     const double inv_bs = 1.0 / bound_scale;
     DIAG_LANE_ADD(8 * (KC == 1) + 6, 1);  // shell searches
+#ifdef PCR_DIAG
+    unsigned long long diag_rows = 0, dg_c = 0, dg_l = 0, dg_r = 0, dg_s = 0, dg_sh = 0;
+    const unsigned long long diag_t0 = DIAG_T();
+#define DG(x) ++(x)
+#else
+#define DG(x) \
+    do {      \
+    } while (0)
+#endif
     for (int r = r_start; r <= rmax;) {
         DIAG_LANE_ADD(8 * (KC == 1) + 7, 1);  // shells
+        DG(dg_sh);
         const int x0 = max(cx - r, 0), x1 = min(cx + r, gx - 1);
         const int y0 = max(cy - r, 0), y1 = min(cy + r, gy - 1);
         const int z0 = max(cz - r, 0), z1 = min(cz + r, gz - 1);
@@ -305,26 +315,51 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
         // the ball cuts out of it, a row's cells to the chord (one cell of slack either side; the radius is a float
         // square root rounded up), and a row is pruned with the K-th distance of the moment.  A query hovering
         // above a dense surface thus opens the few rows below it, not the whole box. ----
-        int rz = z0 - 1, ry = 0, ylast = -1, seg = 0;  // ry > ylast: the layer is used up
+        // Order: first the "cross" through the query's own cell -- its row in every layer, then every row of its own
+        // layer -- and only then the rest, layer by layer.  The cross is cheap (two lines of rows) and meets every
+        // nearby surface close to the point where that surface is nearest, so the K-th distance is tight before
+        // the bulk of the box is looked at, most of which is then pruned unopened.
+        int rz = z0 - 1, ry = 0, ylast = -1, seg = 0, phase = 0;  // ry > ylast: the layer is used up
         bool layer_start = false, alive = true;
         double dz2 = 0.0;
         uint32_t p = 0, e = 0;
         while (alive) {
             if (p < e) {
-                DIAG_LANE_ADD(8 * (KC == 1) + 4, 1);  // candidates of the shell search
-                const Pt4 c = cand[p];
-                const double d = cand_d2<XF>(xf, qx, qy, qz, c);
-                const uint32_t ci = (uint32_t)c.w;
-                if (better(d, ci, wd, wi)) {
-                    top.insert(d, ci);
-                    wd = top.worst_d();
-                    wi = top.worst_i();
+                // PCR_WALK_UNROLL candidates per trip, as in the ring walk: their loads are in flight together and
+                // the trip's bookkeeping is paid once.  Slots past the end re-read the last candidate and are ignored.
+                DG(dg_c);
+                Pt4 c[PCR_WALK_UNROLL];
+                const uint32_t last = e - 1, left = e - p;
+#pragma unroll
+                for (int u = 0; u < PCR_WALK_UNROLL; ++u) c[u] = cand[min(p + (uint32_t)u, last)];
+                p += min(left, (uint32_t)PCR_WALK_UNROLL);
+                DIAG_LANE_ADD(8 * (KC == 1) + 4, min(left, (uint32_t)PCR_WALK_UNROLL));  // candidates of the shell search
+#pragma unroll
+                for (int u = 0; u < PCR_WALK_UNROLL; ++u) {
+                    const double d = cand_d2<XF>(xf, qx, qy, qz, c[u]);
+                    const uint32_t ci = (uint32_t)c[u].w;
+                    if (((uint32_t)u < left) & better(d, ci, wd, wi)) {
+                        top.insert(d, ci);
+                        wd = top.worst_d();
+                        wi = top.worst_i();
+                    }
                 }
-                ++p;
-            } else if (ry > ylast) {  // the next layer
-                if (++rz > z1) {
-                    alive = false;
-                } else {
+            } else if (ry > ylast) {  // the next layer, or the next phase
+                DG(dg_l);
+                ++rz;
+                if (phase == 1) {  // the query's own layer is done: now all the others
+                    phase = 2;
+                    rz = z0;
+                }
+                if (rz > z1) {
+                    if (phase == 0) {  // the query's row has been seen in every layer: now its own layer
+                        phase = 1;
+                        rz = cz;
+                    } else {
+                        alive = false;
+                    }
+                }
+                if (alive & !((phase == 2) & (rz == cz))) {
                     const double dz = slab_gap(sz, g.lo[2], rz, g.h, margin);
                     dz2 = dz * dz;
                     const double rem_z = fmin(wd, max_d2) * inv_bs - dz2;
@@ -335,9 +370,15 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
                         hi_c = fmax(fmin(hi_c, (double)y1), (double)y0 - 1.0);
                         ry = (int)lo_c;
                         ylast = (int)hi_c;
+                        if (phase == 0) {  // only the query's own row
+                            ry = max(ry, cy);
+                            ylast = min(ylast, cy);
+                        }
                         layer_start = true;
                     }
                 }
+            } else if ((phase != 0) & (ry == cy)) {  // the query's own row was handled in the first phase
+                ++ry;
             } else {  // row ry of layer rz (its next segment)
                 bool skip = false;
                 if constexpr (WINDOW) {
@@ -349,7 +390,9 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
                     }
                 }
                 layer_start = false;
+                DG(dg_r);
                 if (skip) {
+                    DG(dg_s);
                     ry = (ry | 7) + 1;
                 } else {
                     const bool inner = (ry >= py0) & (ry <= py1) & (rz >= pz0) & (rz <= pz1);
@@ -378,6 +421,7 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
                             xe = (int)hi_c;
                             if (xs <= xe) {
                                 DIAG_LANE_ADD(8 * (KC == 1) + 3, 1);  // rows opened by the shell search
+                                DG(diag_rows);
                                 const size_t base = ((size_t)rz * gy + ry) * gx;
                                 p = cs[base + xs];
                                 e = cs[base + xe + 1];
@@ -421,6 +465,21 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
         }
         r = min(rn, rmax);  // at r == rmax the box is the whole grid and the loop ends through `all`
     }
+#ifdef PCR_DIAG
+    {
+        const unsigned long long dt = dg_c + dg_l + dg_r;
+        if (atomicMax(&g_diag[24], dt) < dt) {  // the shell search with the most trips so far: what did it do?
+            g_diag[25] = dg_c;
+            g_diag[26] = dg_l;
+            g_diag[27] = dg_r;
+            g_diag[28] = dg_s;
+            g_diag[29] = dg_sh;
+            g_diag[30] = diag_rows;
+            g_diag[31] = (unsigned long long)(g.h * 1e6);
+        }
+    }
+#endif
+#undef DG
 }
 
 

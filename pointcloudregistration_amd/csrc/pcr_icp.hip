@@ -873,10 +873,10 @@ int pcr_fit_read(pcr_fit *f, double R[9], double T[3], uint32_t *iterations, int
 }  // extern "C"
 
 #ifdef PCR_DIAG
-extern "C" int pcr_diag_read_icp(unsigned long long out[16], int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcr::g_diag), sizeof(unsigned long long) * 16) != hipSuccess) return -2;
+extern "C" int pcr_diag_read_icp(unsigned long long out[32], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcr::g_diag), sizeof(unsigned long long) * 32) != hipSuccess) return -2;
     if (reset) {
-        unsigned long long z[16] = {0};
+        unsigned long long z[32] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(pcr::g_diag), z, sizeof z) != hipSuccess) return -2;
     }
     return 0;
