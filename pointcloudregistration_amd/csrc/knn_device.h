@@ -319,7 +319,8 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
         // layer -- and only then the rest, layer by layer.  The cross is cheap (two lines of rows) and meets every
         // nearby surface close to the point where that surface is nearest, so the K-th distance is tight before
         // the bulk of the box is looked at, most of which is then pruned unopened.
-        int rz = z0 - 1, ry = 0, ylast = -1, seg = 0, phase = 0;  // ry > ylast: the layer is used up
+        // (Only worth its extra trips in a large shell; a small one is scanned plainly: phase 3.)
+        int rz = z0 - 1, ry = 0, ylast = -1, seg = 0, phase = r >= 8 ? 0 : 3;  // ry > ylast: the layer is used up
         bool layer_start = false, alive = true;
         double dz2 = 0.0;
         uint32_t p = 0, e = 0;
@@ -377,7 +378,7 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
                         layer_start = true;
                     }
                 }
-            } else if ((phase != 0) & (ry == cy)) {  // the query's own row was handled in the first phase
+            } else if (((phase == 1) | (phase == 2)) & (ry == cy)) {  // the query's own row was handled in phase 0
                 ++ry;
             } else {  // row ry of layer rz (its next segment)
                 bool skip = false;
