@@ -107,3 +107,34 @@ def test_step_rejects_bad_arguments(pcr, ctx):
         pcr.icp_step(ctx, six, tix, R, T, 1, 1.0, 1.0, sample_idx=np.array([0, 500], np.uint32))
     out = pcr.icp_step(ctx, six, tix, R, T, 1, 1.0, 1.0, sample_idx=np.empty(0, np.uint32))
     assert out["partials"][0] == 0  # empty sample set: zero sums, no error
+
+
+def test_handles_give_their_device_memory_back(pcr, ctx):
+    """Indices (single grid and nested levels, with their strip tables), clouds and fits are created and destroyed in
+    a loop: the device's free memory must come back to where it was (nothing the library allocates may leak)."""
+    import torch
+    from pointcloudregistration_amd import synth
+    src, tgt, Rm, t = synth.lidar_pair(200_000, 3)
+    usrc, utgt, _, _ = synth.registration_pair(100_000, 100_000, 3)
+
+    def cycle():
+        for a, b in ((src, tgt), (usrc, utgt)):
+            ca, cb = pcr.Cloud(ctx, a), pcr.Cloud(ctx, b)
+            ia, ib = pcr.Index(ctx, ca, kind=pcr.INDEX_GRID), pcr.Index(ctx, cb, kind=pcr.INDEX_GRID)
+            U = ib.unique_sq_dist()
+            fit = pcr.Fit(ctx, ia, ib, 4, U * 36.0, U * 4.0, pcr.ConvergenceParams.regcfg(3), U)
+            out = fit.run(np.eye(3).reshape(9), np.zeros(3), 3)
+            assert out["iterations"] >= 1
+            ib.knn(a[:5000], 4)
+            pcr.sample_grid(ctx, ia)
+            fit.close(); ia.close(); ib.close(); ca.close(); cb.close()
+        ctx.synchronize()
+
+    cycle()                                   # warm: grow-only scratch of the context reaches its size
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(5):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, (free0, free1)
