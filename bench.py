@@ -37,14 +37,14 @@ def algorithmic_bytes_per_sample(k):
 
 
 def committed_traffic(kernel_prefix, points, k):
-    """HBM bytes per launch of the step kernel from the PMC passes committed under profiles/ (FETCH_SIZE x 2
-    [gfx950 correction] + WRITE_SIZE, see tools/summarize_profile.py).  Counters cannot be collected from
+    """(HBM bytes, source file, VALU wave instructions) per launch of the step kernel from the PMC passes committed
+    under profiles/ (bytes = FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE, see tools/summarize_profile.py).  Counters cannot be collected from
     inside this process; the figure is from `rocprofv3 --pmc` runs of this same command (tools/profile.sh)
     and only applies to the headline workload it was collected on -- otherwise None."""
     if points != 1_000_000 or k != 4:
-        return None, None
+        return None, None, None
     import glob
-    best = (None, None)
+    best = (None, None, None)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
         try:
             with open(f) as fh:
@@ -53,7 +53,7 @@ def committed_traffic(kernel_prefix, points, k):
             continue
         for name, e in d.get("kernels", {}).items():
             if name.startswith(kernel_prefix) and "hbm_traffic_bytes" in e:
-                best = (e["hbm_traffic_bytes"], os.path.relpath(f, ROOT))
+                best = (e["hbm_traffic_bytes"], os.path.relpath(f, ROOT), e.get("counters", {}).get("SQ_INSTS_VALU"))
     return best
 
 
@@ -239,7 +239,11 @@ def main():
         algo_bytes = algorithmic_bytes_per_sample(k) * m
         achieved = algo_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
         info = tix.info()
-        traffic, traffic_src = committed_traffic("icp_step_grid_kernel<%d" % k, n, k) if world == 1 else (None, None)
+        traffic, traffic_src, valu_insts = (committed_traffic("icp_step_grid_kernel<%d" % k, n, k) if world == 1
+                                            else (None, None, None))
+        # VALU utilisation (north star): wave instructions x 4 issue cycles over the SIMD-cycles of the launch
+        # (256 CUs x 4 SIMDs at the 2.4 GHz peak engine clock); instruction count from the committed PMC pass
+        valu_util = (valu_insts * 4.0 / (1024 * step_ms * 1e-3 * 2.4e9)) if valu_insts and step_ms > 0 else None
         out = {
             "metric": "icp_iterations_per_s", "value": args.steps / elapsed, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -254,6 +258,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
+                         "valu_insts_per_launch": valu_insts, "valu_utilisation": valu_util,
                          "kernel": f"icp_step_grid_kernel<{k if k in (1, 4, 8, 16, 32) else '>=k'}, false, {'false' if world == 1 else 'true'}>",
                          "kernel_ms_avg": step_ms, "launches": kt["step"][1],
                          "algorithmic_bytes_per_launch": algo_bytes,
