@@ -8,7 +8,7 @@ One "step" = ONE ICRP iteration: transform the source, forward K-NN, reverse 1-N
 device-resident, the host only enqueues).  Inputs and indices are resident in HBM before the timed
 region; index builds are reported separately.
 
-  python bench.py --gpus 1 --steps 30 --warmup 3
+  python bench.py --gpus 1 --steps 30 --warmup 10
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
@@ -93,7 +93,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--points", type=int, default=1_000_000, help="points per cloud (headline: 1M)")
     ap.add_argument("--k", type=int, default=4, help="CorrespondenceEstimationClosestPoints.NN")
     ap.add_argument("--occupancy", type=float, default=0.0, help="grid target occupancy (0 = library default)")
