@@ -69,3 +69,27 @@ def test_solve_rigid_host_only(pcr):
     with pytest.raises(pcr.PcrError) as e:
         pcr.solve_rigid(np.zeros(17), pp, pq, np.eye(3).reshape(9), np.zeros(3))
     assert e.value.status == -5
+
+
+def test_struct_layouts_of_the_binding_match_the_header(pcr, tmp_path):
+    """The ctypes mirrors of the structs that cross the ABI are laid out exactly as a C compiler lays out the header's:
+    a small C program prints sizeof/offsetof, compared field by field (catches a field added on one side only)."""
+    import ctypes
+    import subprocess
+    structs = {"pcr_index_params": pcr.IndexParams, "pcr_index_info": pcr.IndexInfo,
+               "pcr_convergence_params": pcr.ConvergenceParams}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "pcr.h"', 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(ln.split() for ln in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
