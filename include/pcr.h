@@ -188,14 +188,20 @@ int pcr_sample_grid(pcr_ctx *ctx, const pcr_index *index, uint32_t cap, uint32_t
  * flags: PCR_STEP_EXACT_INDICES makes out_fwd/out_rev the reference's values for EVERY sample;
  * without it a sample whose forward distance already fails the gate may report PCR_NO_INDEX in
  * out_fwd/out_rev (keep and partials are identical either way).
- * Outputs out_fwd[m], out_rev[m], out_keep[m] are nullable. */
+ * Outputs out_fwd, out_rev, out_keep are nullable.  WHERE a sample's result goes: with a sample list
+ * (sample_idx != NULL) the arrays hold m entries and entry t belongs to sample_idx[t]; without one
+ * (sample_idx NULL: the samples are source points themselves) the arrays are indexed by ORIGINAL source
+ * index and must hold ALL n source entries -- also for the sub-range [sample_begin, sample_begin+m) of
+ * pcr_icp_step_d, which is a range of the index's internal processing order, not of original indices:
+ * only the entries of the points in that range are written, the others are left untouched. */
 #define PCR_STEP_EXACT_INDICES 1u
 int pcr_icp_step(pcr_ctx *ctx, const pcr_index *src_index, const pcr_index *tgt_index,
                  const uint32_t *sample_idx /*nullable*/, uint32_t m, const double R[9], const double T[3],
                  uint32_t k, double thr_fwd_sq, double thr_rev_sq, uint32_t flags, double partials[17],
                  uint32_t *out_fwd, uint32_t *out_rev, uint8_t *out_keep);
 /* device-resident variant for the multi-GPU loop: sample_idx_d [m] (nullable) on the device,
- * partials_d [17] on the device (ready for an RCCL all-reduce on the same stream). */
+ * partials_d [17] on the device (ready for an RCCL all-reduce on the same stream).  With sample_idx_d NULL the
+ * output arrays need n entries (see above), whatever m is. */
 int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src_index, const pcr_index *tgt_index,
                    const uint32_t *sample_idx_d /*nullable*/, uint32_t sample_begin, uint32_t m,
                    const double R[9], const double T[3], uint32_t k, double thr_fwd_sq, double thr_rev_sq,

@@ -373,6 +373,8 @@ struct FitDev {
     int32_t state;       // pcr_fit_state
     uint32_t traj_cap;
     double last_n;
+    double last_mse;  // MSE of the last completed iteration (what pcr_fit_read reports; cur_mse/pre_mse belong to the
+                      // criteria emulation, whose short-circuit order can leave them one iteration behind)
 };
 
 __global__ void fit_init_kernel(FitDev value, FitDev *dst) { *dst = value; }
@@ -404,6 +406,7 @@ __global__ void fit_solve_kernel(FitDev *F, const double *__restrict__ partials,
     }
     double mse;
     solve_rigid_core(part, F->dyn.pivot_p, F->dyn.pivot_q, R, T, nullptr, nullptr, &mse);
+    F->last_mse = mse;
     if (row) {
         for (int i = 0; i < 9; ++i) row[i] = R[i];
         for (int i = 0; i < 3; ++i) row[9 + i] = T[i];
@@ -818,6 +821,7 @@ int pcr_fit_reset(pcr_fit *f, const double R[9], const double T[3]) {
     // reference: NaN makes the first transformation test false, as garbage far from a rotation does
     I.pre_mse = I.cur_mse = 1.7976931348623157e308;
     for (int i = 0; i < 9; ++i) I.pre_rot[i] = __builtin_nan("");
+    I.last_mse = __builtin_nan("");
     I.similar = 0;
     I.iteration = 0;
     I.state = PCR_FIT_NOT_CONVERGED;
@@ -860,7 +864,7 @@ int pcr_fit_read(pcr_fit *f, double R[9], double T[3], uint32_t *iterations, int
     if (T) memcpy(T, H.dyn.M.t, sizeof(double) * 3);
     if (iterations) *iterations = H.iteration;
     if (state) *state = H.state;
-    if (mse) *mse = H.cur_mse;
+    if (mse) *mse = H.last_mse;
     if (pairs) *pairs = H.last_n;
     if (traj && traj_rows && f->traj_d) {
         uint32_t rows = H.iteration < f->traj_cap ? H.iteration : f->traj_cap;

@@ -219,6 +219,11 @@ void CCorrespondenceEstimationClosestPointsGPU::_determineCorrespondencesV(const
     const SDeviceCloud *pSrc = pSession->acquire(m_pSourcePointCloud), *pTgt = pSession->acquire(m_pTargetPointCloud);
     if (!pSrc || !pTgt) {
         hiveEventLogger::hiveOutputWarning(__EXCEPTION_SITE__, "no device index: " + pSession->lastError());
+        if (pSession->world() > 1) {  // the peers are waiting in this iteration's collective: tell them (see below)
+            double Poison[17];
+            for (int i = 0; i < 17; ++i) Poison[i] = std::numeric_limits<double>::quiet_NaN();
+            pSession->allReduce(Poison);
+        }
         return;
     }
     // every sampler of the reference returns a CIndexSubset over the sampled cloud (SamplerRandom.cpp:49); the
@@ -258,10 +263,17 @@ void CCorrespondenceEstimationClosestPointsGPU::_determineCorrespondencesV(const
     }
     if (Status != PCR_OK) {
         warn(__EXCEPTION_SITE__, "pcr_icp_step", Status);
-        return;
+        if (World == 1) return;
+        // a sharded run: the other ranks are about to enter the collective -- enter it too, with poisoned partials,
+        // so that every rank sees the failure and stops in the same iteration instead of blocking for ever
+        for (int i = 0; i < 17; ++i) pStep->Partials[i] = std::numeric_limits<double>::quiet_NaN();
     }
     if (pSession->allReduce(pStep->Partials) != 0) {
         hiveEventLogger::hiveOutputWarning(__EXCEPTION_SITE__, "all-reduce of the step partials failed");
+        return;
+    }
+    if (!(pStep->Partials[0] == pStep->Partials[0])) {  // NaN: this rank or a peer failed its share
+        hiveEventLogger::hiveOutputWarning(__EXCEPTION_SITE__, "a rank of the sharded step failed; no correspondences this iteration");
         return;
     }
     pcr_icp_pivots(pSrc->pIndex, pTgt->pIndex, vR.data(), vT.data(), pStep->PivotP, pStep->PivotQ);

@@ -219,6 +219,9 @@ bool CIterativeFit::__fitLoopFused(Eigen::Matrix3d &vioR, ColVector3 &vioT) {
     uint32_t Iterations = 0;
     int State = PCR_FIT_NOT_CONVERGED;
     unsigned int Enqueued = 0;
+    // read into temporaries: a failure half-way must leave the caller's (R,T) untouched, so that the stage-by-stage
+    // loop the caller falls back to starts from where this one started, not from a partially advanced transform
+    double ReadR[9], ReadT[3];
     while (Status == PCR_OK) {
         // a batch of iterations without the host in between; once the criteria fire the rest of a batch is no-ops
         const unsigned int Batch = std::min(16u, Budget - Enqueued);
@@ -227,7 +230,7 @@ bool CIterativeFit::__fitLoopFused(Eigen::Matrix3d &vioR, ColVector3 &vioT) {
             if (Status == PCR_OK) Status = pcr_fit_enqueue_solve(pFit);
         }
         Enqueued += Batch;
-        if (Status == PCR_OK) Status = pcr_fit_read(pFit, vioR.data(), vioT.data(), &Iterations, &State, NULL, NULL, NULL, 0);
+        if (Status == PCR_OK) Status = pcr_fit_read(pFit, ReadR, ReadT, &Iterations, &State, NULL, NULL, NULL, 0);
         if (Iterations < Enqueued || Enqueued >= Budget) break;  // stopped by itself, or out of budget
     }
     if (Status == PCR_OK && m_Observer && Iterations) {
@@ -242,6 +245,8 @@ bool CIterativeFit::__fitLoopFused(Eigen::Matrix3d &vioR, ColVector3 &vioT) {
         hiveEventLogger::hiveOutputWarning(__EXCEPTION_SITE__, std::string("device-resident loop: ") + pcr_strerror(Status) + " -- " + pcr_last_error());
         return false;
     }
+    std::copy(ReadR, ReadR + 9, vioR.data());
+    std::copy(ReadT, ReadT + 3, vioT.data());
     m_NumIterations = Iterations;
     pConfig->set(CBaseConvergenceCriteria::getKeyConvergenceState(), State < 0 ? 0 : State);
     return true;
