@@ -209,6 +209,20 @@ int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src_index, const pcr_index *tg
                    uint8_t *out_keep_d);
 int pcr_icp_pivots(const pcr_index *src_index, const pcr_index *tgt_index, const double R[9],
                    const double T[3], double pivot_p[3], double pivot_q[3]);
+/* pcr_icp_step_d for callers that CANNOT ALLOCATE: code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  No counterpart in the reference.  Same arguments, same results bit for bit, but the
+ * step's scratch (per-iteration constants + per-block partial sums) lives in a fixed device array inside the
+ * library (about 2.1 MiB, held by every GPU the library runs on until the process ends) instead of context-owned
+ * allocations: the call performs no hipMalloc / hipFree, whatever its arguments.  Limits: m <= PCR_NOALLOC_MAX_SAMPLES
+ * (larger m is rejected with PCR_E_INVALID: split the samples into ranges and add the partials); all calls on one
+ * GPU share that GPU's array, so two calls that overlap in time on one GPU (different contexts or streams) race --
+ * serialise them.  Inputs and outputs are the caller's, as for pcr_icp_step_d. */
+#define PCR_NOALLOC_MAX_SAMPLES 4194304u
+int pcr_icp_step_noalloc_d(pcr_ctx *ctx, const pcr_index *src_index, const pcr_index *tgt_index,
+                           const uint32_t *sample_idx_d /*nullable*/, uint32_t sample_begin, uint32_t m,
+                           const double R[9], const double T[3], uint32_t k, double thr_fwd_sq, double thr_rev_sq,
+                           uint32_t flags, double *partials_d, uint32_t *out_fwd_d, uint32_t *out_rev_d,
+                           uint8_t *out_keep_d);
 
 /* ---- the same 17 sums over an EXPLICIT pair list ------------------------------------------
  * Replaces compute3DCentroid x2 + __deMean + __buildPointPairMatrix + H = A*B^T

@@ -73,6 +73,8 @@ SYMBOLS = {
                                C.c_uint32, _dp, _up, _up, _bp]),
     "pcr_icp_step_d": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _dp, _dp, C.c_uint32, C.c_double,
                                  C.c_double, C.c_uint32, _vp, _vp, _vp, _vp]),
+    "pcr_icp_step_noalloc_d": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _dp, _dp, C.c_uint32, C.c_double,
+                                         C.c_double, C.c_uint32, _vp, _vp, _vp, _vp]),
     "pcr_icp_pivots": (C.c_int, [_vp, _vp, _dp, _dp, _dp, _dp]),
     "pcr_fit_create": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, _vp,
                                  C.c_double, C.c_uint32, C.POINTER(_vp)]),
@@ -283,9 +285,13 @@ def icp_step(ctx, src_index, tgt_index, R, T, k, thr_fwd_sq, thr_rev_sq, sample_
     return dict(partials=partials, fwd=fwd, rev=rev, keep=keep)
 
 
+NOALLOC_MAX_SAMPLES = 4194304
+
+
 def icp_step_d(ctx, src_index, tgt_index, R, T, k, thr_fwd_sq, thr_rev_sq, partials_t, sample_begin=0, m=None,
-               sample_idx_t=None, exact=False, out_fwd_t=None, out_rev_t=None, out_keep_t=None, flags=0):
-    """Asynchronous, device-resident step: partials_t is a float64 CUDA tensor of >= 17 elements."""
+               sample_idx_t=None, exact=False, out_fwd_t=None, out_rev_t=None, out_keep_t=None, flags=0, noalloc=False):
+    """Asynchronous, device-resident step: partials_t is a float64 CUDA tensor of >= 17 elements.
+    noalloc: go through pcr_icp_step_noalloc_d (fixed library scratch, no allocation inside the call)."""
     R, T = _rt(R, T)
     if m is None:
         m = sample_idx_t.numel() if sample_idx_t is not None else src_index.n - sample_begin
@@ -293,9 +299,10 @@ def icp_step_d(ctx, src_index, tgt_index, R, T, k, thr_fwd_sq, thr_rev_sq, parti
     def p(t):
         return _vp(t.data_ptr()) if t is not None else None
 
-    _check(lib().pcr_icp_step_d(ctx.h, src_index.h, tgt_index.h, p(sample_idx_t), sample_begin, m, _d(R), _d(T), k,
-                                thr_fwd_sq, thr_rev_sq, (STEP_EXACT_INDICES if exact else 0) | flags, p(partials_t),
-                                p(out_fwd_t), p(out_rev_t), p(out_keep_t)), "pcr_icp_step_d")
+    fn = lib().pcr_icp_step_noalloc_d if noalloc else lib().pcr_icp_step_d
+    _check(fn(ctx.h, src_index.h, tgt_index.h, p(sample_idx_t), sample_begin, m, _d(R), _d(T), k,
+              thr_fwd_sq, thr_rev_sq, (STEP_EXACT_INDICES if exact else 0) | flags, p(partials_t),
+              p(out_fwd_t), p(out_rev_t), p(out_keep_t)), "pcr_icp_step_noalloc_d" if noalloc else "pcr_icp_step_d")
 
 
 def icp_pivots(src_index, tgt_index, R, T):

@@ -673,6 +673,10 @@ int pcr_ctx_create(int device, pcr_ctx **out) {
                        prop.gcnArchName);
         return PCR_E_NO_DEVICE;
     }
+    {
+        const int rc = noalloc_scratch_init(device);  // once per device: the fixed scratch of pcr_icp_step_noalloc_d
+        if (rc != PCR_OK) return rc;
+    }
     pcr_ctx *c = new pcr_ctx();
     c->device = device;
     c->profiling = false;

@@ -584,33 +584,49 @@ int pcr_icp_pivots(const pcr_index *src, const pcr_index *tgt, const double R[9]
     return PCR_OK;
 }
 
-int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const uint32_t *sample_idx_d,
-                   uint32_t sample_begin, uint32_t m, const double R[9], const double T[3], uint32_t k,
-                   double thr_fwd_sq, double thr_rev_sq, uint32_t flags, double *partials_d, uint32_t *out_fwd_d,
-                   uint32_t *out_rev_d, uint8_t *out_keep_d) {
-    PCR_REQUIRE(ctx && src && tgt && R && T && partials_d, "pcr_icp_step_d: NULL argument");
+// What pcr_icp_step_d and pcr_icp_step_noalloc_d share: argument checks, the per-iteration constants, the launches.
+// dyn_d and block_partials_d are the step's scratch (device memory beyond inputs and outputs); who owns them is the
+// only difference between the two entry points.
+static int step_enqueue(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const uint32_t *sample_idx_d,
+                        uint32_t sample_begin, uint32_t m, const double R[9], const double T[3], uint32_t k,
+                        double thr_fwd_sq, double thr_rev_sq, uint32_t flags, double *partials_d, uint32_t *out_fwd_d,
+                        uint32_t *out_rev_d, uint8_t *out_keep_d, StepDyn *dyn_d, double *block_partials_d,
+                        const char *who) {
     StepArgs A;
-    int rc = prepare_step_args(ctx, src, tgt, sample_idx_d, sample_begin, m, k, thr_fwd_sq, thr_rev_sq, flags, A,
-                               "pcr_icp_step_d");
+    int rc = prepare_step_args(ctx, src, tgt, sample_idx_d, sample_begin, m, k, thr_fwd_sq, thr_rev_sq, flags, A, who);
     if (rc != PCR_OK) return rc;
-    for (int i = 0; i < 9; ++i) PCR_REQUIRE(isfinite(R[i]), "pcr_icp_step_d: R is not finite");
-    for (int i = 0; i < 3; ++i) PCR_REQUIRE(isfinite(T[i]), "pcr_icp_step_d: T is not finite");
-    PCR_HIP(hipSetDevice(ctx->device));
+    for (int i = 0; i < 9; ++i) PCR_REQUIRE(isfinite(R[i]), "%s: R is not finite", who);
+    for (int i = 0; i < 3; ++i) PCR_REQUIRE(isfinite(T[i]), "%s: T is not finite", who);
     StepDyn D;
     double c_src[3], c_tgt[3], defect = 0;
     cloud_centre(src->cloud, c_src);
     cloud_centre(tgt->cloud, c_tgt);
     PCR_REQUIRE(make_dyn(R, T, c_src, c_tgt, clouds_scale(src->cloud, tgt->cloud), D, &defect),
-                "pcr_icp_step_d: R must be a rotation to within 1e-3 (orthogonality defect %g)", defect);
+                "%s: R must be a rotation to within 1e-3 (orthogonality defect %g)", who, defect);
     A.out_fwd = out_fwd_d;
     A.out_rev = out_rev_d;
     A.out_keep = out_keep_d;
-
     const uint32_t nb = m ? (m + 255) / 256 : 0;
     if (nb == 0) {
         PCR_HIP(hipMemsetAsync(partials_d, 0, sizeof(double) * 17, ctx->stream));
         return PCR_OK;
     }
+    A.block_partials = block_partials_d;
+    A.dyn = dyn_d;
+    // the per-iteration values travel as a kernel argument of a one-thread kernel: stream-ordered, no staging buffer
+    hipLaunchKernelGGL(set_dyn_kernel, dim3(1), dim3(1), 0, ctx->stream, D, dyn_d);
+    launch_step_kernels(ctx, src, A, nb, k, partials_d);
+    PCR_HIP(hipGetLastError());
+    return PCR_OK;
+}
+
+int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const uint32_t *sample_idx_d,
+                   uint32_t sample_begin, uint32_t m, const double R[9], const double T[3], uint32_t k,
+                   double thr_fwd_sq, double thr_rev_sq, uint32_t flags, double *partials_d, uint32_t *out_fwd_d,
+                   uint32_t *out_rev_d, uint8_t *out_keep_d) {
+    PCR_REQUIRE(ctx && src && tgt && R && T && partials_d, "pcr_icp_step_d: NULL argument");
+    PCR_HIP(hipSetDevice(ctx->device));
+    const uint32_t nb = m ? (m + 255) / 256 : 0;
     if ((size_t)nb * 17 > ctx->block_partials_cap) {
         if (ctx->block_partials_d) {
             PCR_HIP(hipStreamSynchronize(ctx->stream));
@@ -621,15 +637,53 @@ int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
         PCR_HIP(hipMalloc(&ctx->block_partials_d, sizeof(double) * 17 * (size_t)nb));
         ctx->block_partials_cap = (size_t)nb * 17;
     }
-    A.block_partials = ctx->block_partials_d;
     StepDyn *dyn_d = (StepDyn *)ctx_scratch(ctx, 5, sizeof(StepDyn));
     if (!dyn_d) return PCR_E_NOMEM;
-    A.dyn = dyn_d;
-    // the per-iteration values travel as a kernel argument of a one-thread kernel: stream-ordered, no staging buffer
-    hipLaunchKernelGGL(set_dyn_kernel, dim3(1), dim3(1), 0, ctx->stream, D, dyn_d);
-    launch_step_kernels(ctx, src, A, nb, k, partials_d);
-    PCR_HIP(hipGetLastError());
+    return step_enqueue(ctx, src, tgt, sample_idx_d, sample_begin, m, R, T, k, thr_fwd_sq, thr_rev_sq, flags, partials_d,
+                        out_fwd_d, out_rev_d, out_keep_d, dyn_d, ctx->block_partials_d, "pcr_icp_step_d");
+}
+
+// ---- the entry point that allocates nothing (include/pcr.h: pcr_icp_step_noalloc_d) ------------------------------
+// Its scratch -- the per-iteration constants and the block partials of the step -- lives in a file-scope device array
+// of fixed size instead of context-owned allocations.  The array's NAME is a host-side stand-in, never a device
+// address: the address is looked up once per device (noalloc_scratch_init, called by pcr_ctx_create with that device
+// current) and only that pointer is ever handed to a kernel.  Every GPU the library runs on holds its own copy until
+// the process ends.
+struct NoAllocScratch {
+    StepDyn dyn;
+    double block_partials[17 * (size_t)(PCR_NOALLOC_MAX_SAMPLES / 256u)];
+};
+static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocScratch)];
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static NoAllocScratch *g_noalloc_ptr[NOALLOC_MAX_DEVICES];  // per device: that device's copy of `scratch`
+
+}  // extern "C"
+namespace pcr {
+int noalloc_scratch_init(int device) {
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES) return PCR_OK;  // such a device simply has no no-alloc entry point
+    if (g_noalloc_ptr[device]) return PCR_OK;
+    void *p = nullptr;
+    PCR_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    g_noalloc_ptr[device] = (NoAllocScratch *)p;
     return PCR_OK;
+}
+}  // namespace pcr
+extern "C" {
+
+int pcr_icp_step_noalloc_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const uint32_t *sample_idx_d,
+                           uint32_t sample_begin, uint32_t m, const double R[9], const double T[3], uint32_t k,
+                           double thr_fwd_sq, double thr_rev_sq, uint32_t flags, double *partials_d,
+                           uint32_t *out_fwd_d, uint32_t *out_rev_d, uint8_t *out_keep_d) {
+    PCR_REQUIRE(ctx && src && tgt && R && T && partials_d, "pcr_icp_step_noalloc_d: NULL argument");
+    PCR_REQUIRE(m <= PCR_NOALLOC_MAX_SAMPLES,
+                "pcr_icp_step_noalloc_d: m=%u exceeds PCR_NOALLOC_MAX_SAMPLES=%u (the fixed scratch of this entry point); "
+                "use pcr_icp_step_d, or split the samples into ranges and add the partials",
+                m, PCR_NOALLOC_MAX_SAMPLES);
+    NoAllocScratch *S = ctx->device < NOALLOC_MAX_DEVICES ? g_noalloc_ptr[ctx->device] : nullptr;
+    PCR_REQUIRE(S, "pcr_icp_step_noalloc_d: no scratch on device %d (set up by pcr_ctx_create)", ctx->device);
+    PCR_HIP(hipSetDevice(ctx->device));
+    return step_enqueue(ctx, src, tgt, sample_idx_d, sample_begin, m, R, T, k, thr_fwd_sq, thr_rev_sq, flags, partials_d,
+                        out_fwd_d, out_rev_d, out_keep_d, &S->dyn, S->block_partials, "pcr_icp_step_noalloc_d");
 }
 
 int pcr_icp_step(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const uint32_t *sample_idx, uint32_t m,

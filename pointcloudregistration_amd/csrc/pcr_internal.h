@@ -126,6 +126,8 @@ struct ProfScope {
 }  // namespace pcr
 
 namespace pcr {
+// looks up this device's copy of the fixed scratch of pcr_icp_step_noalloc_d (pcr_icp.hip); the device must be current
+int noalloc_scratch_init(int device);
 // returns ctx->scratch_d[slot] grown to at least `bytes` (NULL + last error on failure)
 void *ctx_scratch(pcr_ctx *ctx, int slot, size_t bytes);
 // positions [0,n) ordered by the Morton key of the (>=4x4x4-cell) brick their point falls in; exactly one of
