@@ -61,7 +61,8 @@ const char *pcr_version(void);
  *   key 3: 1 = leave K-NN query batches in the caller's order
  *   key 4: how the ICP step gets at the transformed source for its reverse search: 0 = choose by cost (a
  *          materialised copy when about every source point is a sample, else candidate by candidate while searching),
- *          1 = always the copy, 2 = always on the fly */
+ *          1 = always the copy, 2 = always on the fly
+ *   key 5: 1 = the ICP step never uses the fp32-filtered kernel (every candidate goes through the fp64 walk) */
 int pcr_tune(int key, int value);
 
 /* ---- context -----------------------------------------------------------------------

@@ -217,6 +217,17 @@ __global__ void __launch_bounds__(256) pos_of_kernel(const Pt4 *__restrict__ pts
     if (i < n) pos_of[(uint32_t)pts[i].w] = i;
 }
 
+// fp32 key-space copy of a level's points (GridView::shadow)
+__global__ void __launch_bounds__(256) shadow_kernel(const Pt4 *__restrict__ pts, uint32_t n, double lo0, double lo1,
+                                                     double lo2, double sc, float4 *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const Pt4 p = pts[i];
+        out[i] = make_float4((float)((p.x - lo0) * sc), (float)((p.y - lo1) * sc), (float)((p.z - lo2) * sc),
+                             __uint_as_float((uint32_t)p.w));
+    }
+}
+
 __global__ void __launch_bounds__(256) pack_kernel(const double *__restrict__ xyz, uint32_t n, Pt4 *__restrict__ pts,
                                                    uint32_t *__restrict__ pos_of) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -860,8 +871,9 @@ int pcr_index_free(pcr_index *ix) {
     hipSetDevice(ix->ctx->device);
     if (ix->pts_d) hipFree(ix->pts_d);
     if (ix->tpts_d) hipFree(ix->tpts_d);
+    if (ix->shadow_d) hipFree(ix->shadow_d);
     for (int l = 0; l < PCR_MAX_LEVELS; ++l) {
-        if (ix->cs_d[l]) hipFree(ix->cs_d[l]);
+        if (ix->cs_raw_d[l]) hipFree(ix->cs_raw_d[l]);
         if (ix->cs8_d[l]) hipFree(ix->cs8_d[l]);
     }
     if (ix->pos_of_d) hipFree(ix->pos_of_d);
@@ -877,16 +889,18 @@ struct LevelBuild {
     GridGeom G;
     double h;
     uint64_t cells;
-    uint32_t *counts_d;     // [cells+1]: histogram, then exclusive starts; becomes the level's cell table
+    uint32_t *counts_raw;   // the allocation: [cells+3] = one zero entry of padding either side of counts_d, so that the
+                            // filtered search can fetch the four row boundaries cs[c-1..c+2] of any cell c with one load
+    uint32_t *counts_d;     // = counts_raw + 1, [cells+1]: histogram, then exclusive starts; becomes the level's cell table
     uint32_t *tile_sums_d;  // scan scratch
     size_t counts_cap, tiles_cap;
     unsigned long long stats_h[2];  // occupied cells, largest cell
 };
 
 void release(LevelBuild &B) {
-    if (B.counts_d) hipFree(B.counts_d);
+    if (B.counts_raw) hipFree(B.counts_raw);
     if (B.tile_sums_d) hipFree(B.tile_sums_d);
-    B.counts_d = B.tile_sums_d = nullptr;
+    B.counts_raw = B.counts_d = B.tile_sums_d = nullptr;
     B.counts_cap = B.tiles_cap = 0;
 }
 
@@ -913,7 +927,7 @@ void make_geom(const double lo[3], const double hi[3], double h, uint64_t max_ce
 // one trial of the histogram at a given cell size: fills counts (device) and the occupancy statistics
 int histogram_trial(pcr_ctx *ctx, const pcr_cloud *cloud, const uint8_t *lvl_d, uint8_t level, LevelBuild &B,
                     unsigned long long *stats_d) {
-    PCR_HIP(hipMemsetAsync(B.counts_d, 0, sizeof(uint32_t) * (B.cells + 1), ctx->stream));
+    PCR_HIP(hipMemsetAsync(B.counts_raw, 0, sizeof(uint32_t) * (B.cells + 3), ctx->stream));
     PCR_HIP(hipMemsetAsync(stats_d, 0, sizeof(unsigned long long) * 2, ctx->stream));
     hipLaunchKernelGGL(cell_histogram_kernel, dim3(grid_blocks(cloud->n)), dim3(256), 0, ctx->stream, cloud->xyz_d,
                        cloud->n, B.G, lvl_d, level, B.counts_d);
@@ -953,10 +967,11 @@ int choose_cells(pcr_ctx *ctx, const pcr_cloud *cloud, const uint8_t *lvl_d, uin
         make_geom(lo, hi, h, P.max_cells, B.G, h_used, B.cells);
         h = h_used;
         if (B.cells + 1 > B.counts_cap) {
-            if (B.counts_d) hipFree(B.counts_d);
-            B.counts_d = nullptr;
+            if (B.counts_raw) hipFree(B.counts_raw);
+            B.counts_raw = B.counts_d = nullptr;
             B.counts_cap = 0;
-            PCR_HIP(hipMalloc(&B.counts_d, sizeof(uint32_t) * (B.cells + 1)));
+            PCR_HIP(hipMalloc(&B.counts_raw, sizeof(uint32_t) * (B.cells + 3)));
+            B.counts_d = B.counts_raw + 1;
             B.counts_cap = B.cells + 1;
         }
         const size_t tiles = (B.cells + SCAN_TILE - 1) / SCAN_TILE + 1;
@@ -1234,8 +1249,9 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
             V.h = B.h;
             V.inv_h = B.G.inv_h;
             ix->cs_d[l] = B.counts_d;  // the index owns the table from here on
+            ix->cs_raw_d[l] = B.counts_raw;
             ix->cells[l] = B.cells;
-            B.counts_d = nullptr;
+            B.counts_raw = B.counts_d = nullptr;
             B.counts_cap = 0;
             M.levels = l + 1;
             // processing order of "all samples": by grid brick, so that a wave's 64 queries share a small box
@@ -1255,6 +1271,29 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
             BUILD_RC(compute_bounds(ctx, cloud->xyz_d, n, lvl_d, (uint8_t)(l + 1), lo, hi));
         }
         hipLaunchKernelGGL(pos_of_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ix->pts_d, n, ix->pos_of_d);
+        // ---- key-space shadows for the filtered search: one uniform grid only, and only while fp32 still resolves
+        // distances far below a cell (key_delta <= 2^24 of 2^32, i.e. grids up to ~14 000 cells along an axis)
+        if (M.levels == 1) {
+            GridView &V = M.v[0];
+            const uint64_t B_cells0 = ix->cells[0];
+            const double sc = 65536.0 / (sqrt(2.5) * V.h);
+            double ext = 0;
+            for (int a = 0; a < 3; ++a) ext = fmax(ext, V.hi[a] - V.lo[a]);
+            // per-axis error of a coordinate difference in root units: both operands rounded to fp32 (|Q| <= ext + 4h)
+            const double eps = 1.1920928955078125e-07 * (ext + 4.0 * V.h) * sc * 1.01;
+            // |key - S d2| <= 2 sqrt(D) sqrt(3) eps + 3 eps^2 + 8*2^-24 D (fp32 arithmetic) + 4096 (truncation), D <= 2^32
+            const double delta = 2.0 * 65536.0 * 1.7320508075688774 * eps * 1.01 + 3.0 * eps * eps + 2048.0 + 4096.0 + 64.0;
+            if (delta <= 16777216.0 && B_cells0 + 3 < (1ull << 30) && (uint64_t)n < (1ull << 28)) {  // 32-bit byte offsets
+                BUILD_HIP(hipMalloc(&ix->shadow_d, sizeof(float4) * (size_t)n));
+                hipLaunchKernelGGL(shadow_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const Pt4 *)ix->pts_d, n,
+                                   V.lo[0], V.lo[1], V.lo[2], sc, ix->shadow_d);
+                V.shadow = ix->shadow_d;
+                V.key_sc = sc;
+                V.key_S = sc * sc;
+                V.key_invS = 1.0 / V.key_S;
+                V.key_delta = (uint32_t)ceil(delta);
+            }
+        }
         BUILD_HIP(hipStreamSynchronize(ctx->stream));
         BUILD_HIP(hipGetLastError());
         ix->info.kind = kind;
@@ -1264,7 +1303,7 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
         ix->info.mean_occupancy = (double)n / (double)(occupied_total ? occupied_total : 1);
         ix->info.max_occupancy = max_occ;
         ix->info.levels = (uint32_t)M.levels;
-        ix->info.device_bytes = (sizeof(Pt4) * 2 + 8) * (uint64_t)n + 4 * (cells_total + M.levels) + cells_total / 8;
+        ix->info.device_bytes = (sizeof(Pt4) * 2 + 8 + (ix->shadow_d ? 16 : 0)) * (uint64_t)n + 4 * (cells_total + M.levels) + cells_total / 8;
     }
     release(B);
     if (stats_d) hipFree(stats_d);

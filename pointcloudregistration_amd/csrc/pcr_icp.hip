@@ -12,9 +12,13 @@
 #include <math.h>
 #include <string.h>
 #include "knn_device.h"
+#include "fast_search.h"
 #include "solve_core.h"
 #ifndef PCR_STEP_WAVES
 #define PCR_STEP_WAVES 5
+#endif
+#ifndef PCR_FAST_WAVES
+#define PCR_FAST_WAVES 6
 #endif
 
 namespace pcr {
@@ -227,6 +231,115 @@ __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(Step
         }
         keep = passF && dR < A.thr_rev;  // strict < (:98)
     }
+    if (live) {
+        accumulate(acc, keep, px, py, pz, qx, qy, qz, dF, D);
+        if (A.out_fwd) A.out_fwd[slot] = found ? j : PCR_NO_INDEX;
+        if (A.out_rev) A.out_rev[slot] = r;
+        if (A.out_keep) A.out_keep[slot] = keep ? 1 : 0;
+    }
+    block_reduce17(acc, A.block_partials, lb, gridDim.x);
+}
+
+// The same iteration on single-level grids that carry fp32 shadows: both searches go through the filtered walk
+// (fast_search.h) -- fp32 keys select, fp64 decides and verifies -- and a lane whose result that walk cannot vouch for
+// repeats the search with the all-fp64 walk of the kernel above.  The reverse search needs no transformed copy of the
+// source: keys are taken in the SOURCE frame (q mapped back by R^-1; the key error bound is widened by R's deviation
+// from an isometry), and only the few candidates that reach the fp64 stage are moved by (R,T), with
+// CPointCloud::transform's expression.  Every index, flag and sum is bit-identical to icp_step_grid_kernel's (tested).
+template <int KC>
+__global__ void __launch_bounds__(256, PCR_FAST_WAVES) icp_step_fast_kernel(StepArgs A) {
+    const StepDyn *__restrict__ dynp = A.dyn;
+    if (dynp->done) return;  // uniform over the grid
+    const StepDyn D = *dynp;
+    const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t t = lb * 256u + threadIdx.x;
+    const bool live = t < A.m;
+    const GridView &GT = A.tgt.v[0], &GS = A.src.v[0];
+    uint32_t pos = 0, orig = 0, slot = 0;
+    double px = 0, py = 0, pz = 0;
+    if (live) {
+        if (A.sample_idx) {
+            orig = A.sample_idx[t];
+            pos = A.src_pos_of[orig];
+            slot = t;
+        } else {
+            pos = A.src_order[A.sample_begin + t];
+            orig = (uint32_t)A.src.all[pos].w;
+            slot = orig;
+        }
+        const Pt4 s = A.src.all[pos];
+        xform(D.M, s.x, s.y, s.z, px, py, pz);  // CurSrcPoint = R*s + T (:86)
+    }
+    __shared__ uint2 rowtab[9][256];
+    uint2 *my_rows = &rowtab[0][threadIdx.x];
+    // ---- forward: K-th nearest target point of p (:89-92)
+    const double fmax_d2 = A.exact ? PCR_INF : A.thr_fwd;
+    const double fwd_scale = 1.0 - 1.8189894035458565e-12;
+    const bool fin = live && isfinite(px) && isfinite(py) && isfinite(pz);
+    TopK<KC> top;
+    top.init(fmax_d2);
+    bool fwd_done = !fin;
+    if (fin)
+        fwd_done = fast_ring1<KC, false>(GT, GT.pts, px, py, pz, px, py, pz, fmax_d2, PCR_INF, fwd_scale, 0.0, GT.key_delta,
+                                         A.k, top, my_rows, nullptr);
+    if (__any(!fwd_done)) {
+        if (!fwd_done) {
+            top.init(fmax_d2);
+            lane_search<KC>(GT, A.tgt.all, px, py, pz, px, py, pz, fmax_d2, fwd_scale, 0.0, top, my_rows);
+        }
+    }
+    double dF;
+    uint32_t j;
+    top.slot(A.k, dF, j);  // NeighborSet.back() = K-th nearest (:91-92)
+    const bool found = fin && j != PCR_NO_INDEX && dF < fmax_d2;
+    const bool passF = found && dF < A.thr_fwd;  // strict < (:97)
+
+    // ---- reverse: nearest TRANSFORMED source point of q (:94-95), seeded with the sample's own image (distance dF)
+    const bool need_rev = found && (passF || A.exact);
+    double qx = 0, qy = 0, qz = 0, sx = 0, sy = 0, sz = 0;
+    if (need_rev) {
+        const Pt4 qpt = A.tgt.all[A.tgt.pos_of[j]];
+        qx = qpt.x;
+        qy = qpt.y;
+        qz = qpt.z;
+        const double ux = qx - D.M.t[0], uy = qy - D.M.t[1], uz = qz - D.M.t[2];
+        sx = D.rinv[0] * ux + D.rinv[3] * uy + D.rinv[6] * uz;
+        sy = D.rinv[1] * ux + D.rinv[4] * uy + D.rinv[7] * uz;
+        sz = D.rinv[2] * ux + D.rinv[5] * uy + D.rinv[8] * uz;
+    }
+    TopK<1> rt;
+    rt.d[0] = dF;
+    rt.idx[0] = orig;
+    const bool rev_active = need_rev && isfinite(sx) && isfinite(sy) && isfinite(sz);
+    // key error of the reverse search: the source grid's own, plus |R v|^2 vs |v|^2 (1 - rev_bound_scale >= 3 * the
+    // orthogonality defect) over the key range, plus the rounding of the inverse map at the largest distance of interest
+    const uint32_t rev_delta =
+        GS.key_delta + (uint32_t)fmin((1.0 - D.rev_bound_scale) * 1.1 * 4294967296.0 +
+                                          2.0 * 65536.0 * 1.01 * D.rev_extra_margin * GS.key_sc + 2.0,
+                                      1073741824.0);
+    bool rev_done = !rev_active;
+    if (rev_active)
+        rev_done = fast_ring1<1, true>(GS, GS.pts, qx, qy, qz, sx, sy, sz, PCR_INF, dF, D.rev_bound_scale, D.rev_extra_margin,
+                                       rev_delta, 1, rt, my_rows, &D.M);
+    if (__any(!rev_done)) {
+        if (!rev_done) {
+            rt.d[0] = dF;
+            rt.idx[0] = orig;
+            lane_search<1, true>(GS, A.src.all, qx, qy, qz, sx, sy, sz, PCR_INF, D.rev_bound_scale, D.rev_extra_margin, rt,
+                                 my_rows, &D.M);
+        }
+    }
+    uint32_t r = PCR_NO_INDEX;
+    bool keep = false;
+    if (need_rev) {
+        r = rt.idx[0];
+        const Pt4 sp = A.src.all[r == orig ? pos : A.src_pos_of[r]];
+        const double dR = cand_d2<true>(&D.M, px, py, pz, sp);  // (CurSrcPoint - TmpPoint).squaredNorm()
+        keep = passF && dR < A.thr_rev;                          // strict < (:98)
+    }
+    double acc[17];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) acc[i] = 0.0;
     if (live) {
         accumulate(acc, keep, px, py, pz, qx, qy, qz, dF, D);
         if (A.out_fwd) A.out_fwd[slot] = found ? j : PCR_NO_INDEX;
@@ -497,6 +610,22 @@ static void launch_step_kernels(pcr_ctx *ctx, const pcr_index *src, const StepAr
     // plus a launch, moving candidates on the fly ~24 us per million SAMPLES (measured, 1 M x 1 M, K=4).  A rank of a
     // sharded fit, or a sampled fit, searches on the fly; a single GPU running every point as a sample copies.
     // tune 4: 0 = by this rule, 1 = always copy, 2 = always on the fly.
+    // single-level grids with fp32 shadows and K <= 4: the filtered kernel (tune 5: 1 = never, for A/B runs and tests)
+    const bool fast = src->kind == PCR_INDEX_GRID && g_tune[5] != 1 && k <= 4 && A.src.levels == 1 && A.tgt.levels == 1 &&
+                      A.src.v[0].shadow && A.tgt.v[0].shadow;
+    if (fast) {
+        {
+            ProfScope ps(ctx, PCR_PROF_STEP);
+            if (k == 1)
+                hipLaunchKernelGGL(icp_step_fast_kernel<1>, dim3(nb), dim3(256), 0, ctx->stream, A);
+            else
+                hipLaunchKernelGGL(icp_step_fast_kernel<4>, dim3(nb), dim3(256), 0, ctx->stream, A);
+        }
+        ProfScope ps(ctx, PCR_PROF_FOLD);
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(17), dim3(256), 0, ctx->stream, (const double *)A.block_partials, nb,
+                           partials_d);
+        return;
+    }
     const bool on_the_fly = src->kind == PCR_INDEX_GRID &&
                             (g_tune[4] == 2 || (g_tune[4] == 0 && 24.0 * (double)A.m < 11.2 * (double)src->n + 6.0e6));
     if (!on_the_fly) {

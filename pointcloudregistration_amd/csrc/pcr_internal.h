@@ -52,6 +52,16 @@ struct GridView {
     double margin;        // absolute safety margin on face distances, ~2^-40 * coordinate scale
     int g[3];             // grid dimensions
     uint32_t n;
+    // ---- fp32 "key space" copy of the points for the filtered search (fast_search.h); NULL when the index has none
+    // (brute force, nested levels, grids so large that fp32 resolves too little).  shadow[i] = (pts[i] - lo) * key_sc
+    // rounded to fp32 (w: the original index, as bits).  key_sc is chosen so that a squared distance of 2.5 h^2 --
+    // above every distance the 3x3x3 walk can settle -- maps to 2^32: a candidate's squared distance, computed in
+    // fp32 from the shadows and truncated, is a 32-bit integer KEY that orders candidates almost like the exact fp64
+    // distance does; key_delta bounds |key - exact| for every query within 4 cells of the grid's box (both roundings
+    // to fp32, the fp32 arithmetic, the truncation), in key units.  The exact fp64 arithmetic decides every result.
+    const float4 *shadow;
+    double key_sc, key_S, key_invS;  // key = key_S * d2, key_S = key_sc^2
+    uint32_t key_delta;
 };
 
 // An index is a small stack of such grids over DISJOINT subsets of the cloud ("levels"): level 0 spans the whole
@@ -158,10 +168,12 @@ struct pcr_index {
     uint32_t n;
     pcr::Pt4 *pts_d;    // [n] cell order (GRID) / original order (BRUTE)
     pcr::Pt4 *tpts_d;   // [n] same order, transformed by the current (R,T) -- scratch of the ICP step
+    float4 *shadow_d;   // [n] same order: fp32 key-space copy (GridView::shadow), single-level grids only
     uint32_t *pos_of_d; // [n] original index -> position in pts_d
     uint32_t *order_d;  // [n] positions in pts_d ordered by grid brick: the processing order of "all samples"
     pcr::MultiView view;
     uint32_t *cs_d[pcr::PCR_MAX_LEVELS];    // [cells+1] of every level, positions relative to the level's segment
+    uint32_t *cs_raw_d[pcr::PCR_MAX_LEVELS];  // the allocations behind cs_d: cs_d - 1, [cells+3] (a zero entry either side)
     uint64_t cells[pcr::PCR_MAX_LEVELS];
     uint32_t *cs8_d[pcr::PCR_MAX_LEVELS];   // strip tables (GridView::cs8)
     pcr_index_info info;

@@ -103,3 +103,33 @@ def test_transformed_copy_and_on_the_fly_reverse_search_agree_bit_for_bit(pcr, c
             for key in ("fwd", "rev", "keep", "partials"):
                 assert (a[key] == b[key]).all(), (mode, key)
     assert out[1][0]["partials"][0] > 10000
+
+
+def test_filtered_kernel_equals_the_fp64_walk_bit_for_bit(pcr, ctx):
+    """The fp32-filtered step kernel (fp32 keys select, fp64 decides and verifies; fast_search.h) against the kernel in
+    which every candidate goes through the fp64 walk (pcr_tune key 5 = 1): every index, flag and partial sum."""
+    from pointcloudregistration_amd import synth
+    for n, seed in ((150000, 41), (30000, 42)):
+        src, tgt, Rm, t = synth.registration_pair(n, n, seed)
+        six, tix = pcr.Index(ctx, pcr.Cloud(ctx, src), kind=pcr.INDEX_GRID), pcr.Index(ctx, pcr.Cloud(ctx, tgt), kind=pcr.INDEX_GRID)
+        U = tix.unique_sq_dist()
+        smp = np.random.default_rng(6).choice(n, n // 7, replace=False).astype(np.uint32)
+        transforms = [synth.coarse_initial_transform(Rm, t, n), (np.eye(3).reshape(9), np.zeros(3)),
+                      (synth.colmajor(Rm), t)]
+        for R, T in transforms:
+            out = {}
+            try:
+                for mode in (1, 0):
+                    pcr.lib().pcr_tune(5, mode)
+                    out[mode] = [pcr.icp_step(ctx, six, tix, R, T, 4, U * 36.0, U * 4.0, exact=True),
+                                 pcr.icp_step(ctx, six, tix, R, T, 4, U * 36.0, U * 4.0, exact=False),
+                                 pcr.icp_step(ctx, six, tix, R, T, 1, U * 36.0, U * 4.0, exact=True),
+                                 pcr.icp_step(ctx, six, tix, R, T, 2, U * 36.0, U * 4.0, sample_idx=smp, exact=True),
+                                 pcr.icp_step(ctx, six, tix, R, T, 3, U * 9.0, U * 1.0, sample_idx=smp, exact=False)]
+            finally:
+                pcr.lib().pcr_tune(5, 0)
+            for a, b in zip(out[1], out[0]):
+                for key in ("fwd", "rev", "keep", "partials"):
+                    assert (a[key] == b[key]).all(), (n, key, int((a[key] != b[key]).sum()))
+        six.close()
+        tix.close()
