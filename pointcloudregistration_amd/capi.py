@@ -13,7 +13,8 @@ import numpy as np
 import torch  # noqa: F401  (must precede loading libpcr.so, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpcr.so")
+# PCR_LIB: developer aid for A/B runs of differently built variants of the library (never set in tests or by the driver)
+LIB_PATH = os.environ.get("PCR_LIB") or os.path.join(_HERE, "libpcr.so")
 
 NO_INDEX = 0xFFFFFFFF
 MAX_K = 32

@@ -38,6 +38,19 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
     return max(min(a, b), min(max(a, b), c));  // selected as one v_med3_u32
 }
 
+// A cell's edge in root units: key_sc = KEY_CELL / h in every grid (pcr_core.hip), 2.5 h^2 <-> 2^32 keys.
+#define KEY_CELL 41448.97f
+// One axis: the cell the key-space coordinate Q falls in (clamped to the grid), and the distances from Q to that cell's
+// low and high face, each shrunk by eps and clamped at 0.
+__device__ __forceinline__ void cell_and_gaps(float Q, int g, float eps, int &c, float &gl, float &gh) {
+    float t = Q * (1.0f / KEY_CELL);
+    t = fminf(fmaxf(t, 0.0f), (float)(g - 1));  // NaN -> 0
+    c = (int)t;
+    const float face = (float)c * KEY_CELL;
+    gl = fmaxf(Q - face - eps, 0.0f);
+    gh = fmaxf(face + KEY_CELL - Q - eps, 0.0f);
+}
+
 // floor / ceiling in key units of a squared distance in cloud units, conservative and saturating
 __device__ __forceinline__ uint32_t key_floor(double v, double S) {
     const double k = fmin(v * S * (1.0 - 9.5367431640625e-07), 4294967295.0);
@@ -63,6 +76,34 @@ struct TopKeys {
     }
 };
 
+// The k-th smallest of N (d2, index) pairs under the total order (d2, index), by ranking: every pair is compared once;
+// of two equal pairs (only placeholders are ever equal) the earlier one ranks first.  Everything statically indexed.
+template <int N>
+__device__ __forceinline__ void kth_of(const double *d, const uint32_t *i, int k, double &dk, uint32_t &ik) {
+    uint32_t rank[N];
+#pragma unroll
+    for (int a = 0; a < N; ++a) rank[a] = 0;
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+#pragma unroll
+        for (int b = a + 1; b < N; ++b) {
+            const bool b_first = better(d[b], i[b], d[a], i[a]);
+            rank[a] += b_first ? 1u : 0u;
+            rank[b] += b_first ? 0u : 1u;
+        }
+    dk = d[0];
+    ik = i[0];
+#pragma unroll
+    for (int a = 1; a < N; ++a) {
+        const bool sel = rank[a] == (uint32_t)(k - 1);
+        dk = sel ? d[a] : dk;
+        ik = sel ? i[a] : ik;
+    }
+    if constexpr (N > 1) {
+        // (rank[0] == k-1 is the default; any other match has overwritten it)
+    }
+}
+
 // One lane, one query, the 3x3x3 cells around it.
 //   g          a single-level grid WITH shadows (g.shadow != NULL)
 //   exact_pts  the fp64 records the distances that decide are evaluated against (g.pts)
@@ -72,61 +113,63 @@ struct TopKeys {
 //   max_d2     as in grid_search: candidates at or beyond are of no interest
 //   bound_d2   a squared distance the K-th best is known not to exceed (+inf: nothing known); prunes from the start
 //   delta      key-space error bound for this search
-//   k          the rank the caller will read (1..KC)
-//   top        initialised by the caller (init(max_d2), or seeded); on return true it holds the exact result
+//   k          the rank wanted (1..KC)
+//   SEEDED     (seed_d, seed_i) is a member of the searched set whose exact distance the caller knows (the reverse
+//              search of the ICP step: the sample's own image); it takes part in the ranking
+//   out_d/out_i  on return true: the k-th smallest (d2, index) exactly -- (max_d2, PCR_NO_INDEX) if fewer than k
+//              candidates lie below max_d2
 // Returns false when this search cannot vouch for the result (not settled within ring 1, a cell row too long for the
-// payload, a query far outside the grid, an unresolved near-tie): the caller re-initialises `top` and runs lane_search.
-template <int KC, bool XF>
-__device__ __forceinline__ bool fast_ring1(const GridView &g, const Pt4 *__restrict__ exact_pts, double qx, double qy,
+// payload, a query far outside the grid, an unresolved near-tie): the caller runs lane_search instead.
+// GV, RG: GridView and Rigid in whatever address space the caller keeps them (the step kernel: the constant one,
+// so that every field is a scalar load at its point of use).
+template <int KC, bool XF, bool SEEDED, class GV, class RG>
+__device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ exact_pts, double qx, double qy,
                                            double qz, double sx, double sy, double sz, double max_d2, double bound_d2,
                                            double bound_scale, double extra_margin, uint32_t delta, int k,
-                                           TopK<KC> &top, uint2 *rowtab, const Rigid *xf) {
+                                           double seed_d, uint32_t seed_i, double &out_d, uint32_t &out_i,
+                                           uint2 *rowtab, const RG *xf) {
     constexpr int KP = KC + 2;
     constexpr int U = PCR_FAST_U;
     const uint32_t *__restrict__ cs = g.cs;
     const float4 *__restrict__ shadow = g.shadow;
     const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
-    const int cx = cell_coord(sx, g.lo[0], g.inv_h, gx);
-    const int cy = cell_coord(sy, g.lo[1], g.inv_h, gy);
-    const int cz = cell_coord(sz, g.lo[2], g.inv_h, gz);
-    const double margin = g.margin + extra_margin + 9.094947017729282e-13 * (fabs(sx) + fabs(sy) + fabs(sz));
     const double S = g.key_S;
-    // ---- geometry in fp64, exactly as ring1_pruned: gaps to the faces of the own cell, the settle bound
-    double gl, gh;
-    gl = sx - (g.lo[0] + (double)cx * g.h) - margin;
-    gh = (g.lo[0] + (double)(cx + 1) * g.h) - sx - margin;
-    gl = gl > 0.0 ? gl : 0.0;
-    gh = gh > 0.0 ? gh : 0.0;
-    const double fxl = gl, fxh = gh;
-    const uint32_t gxl_k = key_floor(gl * gl * bound_scale, S), gxh_k = key_floor(gh * gh * bound_scale, S);
-    gl = sy - (g.lo[1] + (double)cy * g.h) - margin;
-    gh = (g.lo[1] + (double)(cy + 1) * g.h) - sy - margin;
-    gl = gl > 0.0 ? gl : 0.0;
-    gh = gh > 0.0 ? gh : 0.0;
-    const double fyl = gl, fyh = gh;
-    const uint32_t gyl_k = key_floor(gl * gl * bound_scale, S), gyh_k = key_floor(gh * gh * bound_scale, S);
-    gl = sz - (g.lo[2] + (double)cz * g.h) - margin;
-    gh = (g.lo[2] + (double)(cz + 1) * g.h) - sz - margin;
-    gl = gl > 0.0 ? gl : 0.0;
-    gh = gh > 0.0 ? gh : 0.0;
-    const double fzl = gl, fzh = gh;
-    const uint32_t gzl_k = key_floor(gl * gl * bound_scale, S), gzh_k = key_floor(gh * gh * bound_scale, S);
-    double settle_b2 = PCR_INF;
-    if (cx > 1) settle_b2 = fmin(settle_b2, (fxl + g.h) * (fxl + g.h));
-    if (cx < gx - 2) settle_b2 = fmin(settle_b2, (fxh + g.h) * (fxh + g.h));
-    if (cy > 1) settle_b2 = fmin(settle_b2, (fyl + g.h) * (fyl + g.h));
-    if (cy < gy - 2) settle_b2 = fmin(settle_b2, (fyh + g.h) * (fyh + g.h));
-    if (cz > 1) settle_b2 = fmin(settle_b2, (fzl + g.h) * (fzl + g.h));
-    if (cz < gz - 2) settle_b2 = fmin(settle_b2, (fzh + g.h) * (fzh + g.h));
-    settle_b2 *= bound_scale * (1.0 - 4.440892098500626e-16);
-    // ---- the query in key space; key_delta holds for queries within 4 cells of the box of the points
-    const double pad = 4.0 * g.h;
-    bool ok = (sx >= g.lo[0] - pad) & (sx <= g.hi[0] + pad) & (sy >= g.lo[1] - pad) & (sy <= g.hi[1] + pad) &
-              (sz >= g.lo[2] - pad) & (sz <= g.hi[2] + pad);
-    const float Qx = (float)((sx - g.lo[0]) * g.key_sc), Qy = (float)((sy - g.lo[1]) * g.key_sc),
-                Qz = (float)((sz - g.lo[2]) * g.key_sc);
+    // ---- the query in key space, and the geometry of its cell there, in fp32.  One unit ("root unit") is the square
+    // root of a key unit; a cell's edge is KEY_CELL root units in every grid.  Everything derived below is a bound:
+    // each gap is shrunk by eps, which covers the rounding of Q itself and of every fp32 operation on the way (a few
+    // ulps of the largest coordinate; key_eps is 2^-22 of it), so a gap can only come out too small -- also when the
+    // rounding of Q puts the query into the cell next to the one exact arithmetic would pick (the gaps are measured from
+    // the faces of the cell actually used).  The walk is exact for whatever cell it is centred on.
+    float Qx = (float)((sx - g.lo[0]) * g.key_sc), Qy = (float)((sy - g.lo[1]) * g.key_sc),
+          Qz = (float)((sz - g.lo[2]) * g.key_sc);
+    const float eps = g.key_eps + (float)(extra_margin * g.key_sc) * 1.0001f;
+    // key_delta holds for queries within 4 cells of the box of the points (NaN fails every comparison)
+    bool ok = (Qx >= -4.0f * KEY_CELL) & (Qx <= g.key_ext[0] + 4.0f * KEY_CELL) & (Qy >= -4.0f * KEY_CELL) &
+              (Qy <= g.key_ext[1] + 4.0f * KEY_CELL) & (Qz >= -4.0f * KEY_CELL) & (Qz <= g.key_ext[2] + 4.0f * KEY_CELL);
+    // squared gaps -> keys, rounded down; bound_scale (< 1) as in ring1_pruned
+    const float ksc = (float)bound_scale * 0.999999f;
+    int cx, cy, cz;
+    float glx, ghx, gly, ghy, glz, ghz;
+    cell_and_gaps(Qx, gx, eps, cx, glx, ghx);
+    cell_and_gaps(Qy, gy, eps, cy, gly, ghy);
+    cell_and_gaps(Qz, gz, eps, cz, glz, ghz);
+    uint32_t gxl_k = cvt_u32_sat(glx * glx * ksc), gxh_k = cvt_u32_sat(ghx * ghx * ksc);
+    const uint32_t gyl_k = cvt_u32_sat(gly * gly * ksc), gyh_k = cvt_u32_sat(ghy * ghy * ksc);
+    const uint32_t gzl_k = cvt_u32_sat(glz * glz * ksc), gzh_k = cvt_u32_sat(ghz * ghz * ksc);
+    // When will the K-th best be final?  Whatever lies outside the 3x3x3 box is beyond one of its faces: a whole cell
+    // (less eps) plus the gap to the own cell's face away along that axis; faces on the grid boundary have nothing
+    // beyond them (ring1_pruned, same rule).
+    const float hs = KEY_CELL - eps;
+    float sb = __builtin_huge_valf();
+    if (cx > 1) sb = fminf(sb, glx + hs);
+    if (cx < gx - 2) sb = fminf(sb, ghx + hs);
+    if (cy > 1) sb = fminf(sb, gly + hs);
+    if (cy < gy - 2) sb = fminf(sb, ghy + hs);
+    if (cz > 1) sb = fminf(sb, glz + hs);
+    if (cz < gz - 2) sb = fminf(sb, ghz + hs);
+    const double settle_b2 = (double)(sb * sb * ksc) * g.key_invS;
     // what is known about the K-th distance before the walk: the caller's bound, and the reach of interest
-    const uint32_t bound_k = key_ceil(fmin(bound_d2, max_d2), S);
+    uint32_t bound_k = key_ceil(fmin(bound_d2, max_d2), S);
     const uint32_t UB0 = sat_add(bound_k, delta);
     // ---- phase 1: the (up to) nine rows, straight-line -- every cell-table load of the search is in flight at once.
     // The four boundaries cs[c-1..c+2] of a row's three cells come with ONE 16-byte buffer load (the table is padded by
@@ -211,18 +254,28 @@ __device__ __forceinline__ bool fast_ring1(const GridView &g, const Pt4 *__restr
             float D = dx * dx;
             D = fmaf(dy, dy, D);
             D = fmaf(dz, dz, D);
-            T.insert((uint32_t)u < tot ? ((cvt_u32_sat(D) & KEY_DIST_MASK) | pay[u]) : KEY_SENTINEL);
+            uint32_t key = (cvt_u32_sat(D) & KEY_DIST_MASK) | pay[u];
+            asm volatile("" : "+v"(key));  // computed in every lane, selected below: no branch per slot
+            T.insert((uint32_t)u < tot ? key : KEY_SENTINEL);
         }
         alive = (p < e) | (ri < cnt);
     }
-    // ---- phase 3: fp64 decides.  The candidates behind the KC smallest keys, exactly; then the verification.
-    auto evaluate = [&](uint32_t key) {
+    // ---- phase 3: fp64 decides.  The candidates behind the KC smallest keys, exactly; the k-th of them by ranking
+    // (every pair compared once); then the verification.
+    constexpr int NS = SEEDED ? 1 : 0;
+    double ed[KC + 1 + NS];
+    uint32_t ei[KC + 1 + NS];
+    auto evaluate = [&](uint32_t key, double &d, uint32_t &ci) {
+        d = max_d2;
+        ci = PCR_NO_INDEX;
         if (key != KEY_SENTINEL) {
             const uint32_t pos = rowtab[((key >> 8) & 15u) * PCR_ROW_STRIDE].x + (key & 255u);
             const Pt4 cnd = exact_pts[pos];
-            const double d = cand_d2<XF>(xf, qx, qy, qz, cnd);
-            const uint32_t ci = (uint32_t)cnd.w;
-            if (better(d, ci, top.worst_d(), top.worst_i())) top.insert(d, ci);
+            const double dd = cand_d2<XF, RG>(xf, qx, qy, qz, cnd);
+            if (dd < max_d2) {
+                d = dd;
+                ci = (uint32_t)cnd.w;
+            }
         }
     };
     // exact squared distance every candidate with a key >= `key` is at least at
@@ -230,24 +283,35 @@ __device__ __forceinline__ bool fast_ring1(const GridView &g, const Pt4 *__restr
         return key == KEY_SENTINEL ? PCR_INF
                                    : (double)sat_sub(key & KEY_DIST_MASK, delta) * g.key_invS * (1.0 - 9.313225746154785e-10);
     };
+    if constexpr (SEEDED) {
+        ed[0] = seed_d;
+        ei[0] = seed_i;
+    }
 #pragma unroll
-    for (int j = 0; j < KC; ++j) evaluate(T.t[j]);
+    for (int j = 0; j < KC; ++j) evaluate(T.t[j], ed[NS + j], ei[NS + j]);
     double ek;
     uint32_t ik;
-    top.slot(k, ek, ik);
+    kth_of<KC + NS>(ed, ei, k, ek, ik);
     double lb = floor_d2(T.t[KC]);
     bool verified = (ek < lb) | (max_d2 <= lb);
     DIAG_LANE_ADD(18 + 4 * XF, (ok & !verified) ? 1 : 0);  // first verification failed
     if (__any(ok & !verified)) {
         DIAG_ADD(26 + XF, 1);  // wave-level second stages
-        if (!verified) evaluate(T.t[KC]);
-        top.slot(k, ek, ik);
-        lb = floor_d2(T.t[KC + 1]);
-        verified |= (ek < lb) | (max_d2 <= lb);
+        evaluate(verified ? KEY_SENTINEL : T.t[KC], ed[KC + NS], ei[KC + NS]);
+        double ek2;
+        uint32_t ik2;
+        kth_of<KC + 1 + NS>(ed, ei, k, ek2, ik2);
+        const double lb2 = floor_d2(T.t[KC + 1]);
+        if (!verified) {
+            ek = ek2;
+            ik = ik2;
+            verified = (ek < lb2) | (max_d2 <= lb2);
+        }
     }
     const bool settled = (ek < settle_b2) | (max_d2 <= settle_b2);
     DIAG_LANE_ADD(19 + 4 * XF, (ok & verified & settled) ? 0 : 1);  // handed to the fp64 walk
-    DIAG_LANE_ADD(28 + XF, cnt);                                    // rows in the table
+    out_d = ek;
+    out_i = ik;
     return ok & verified & settled;
 }
 

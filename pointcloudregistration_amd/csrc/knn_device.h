@@ -52,7 +52,9 @@ __device__ __forceinline__ double sqdist3(double qx, double qy, double qz, doubl
 struct Rigid {
     double r[9], t[3];
 };
-__device__ __forceinline__ void xform(const Rigid &M, double x, double y, double z, double &ox, double &oy,
+// (RG: Rigid in any address space -- the filtered kernel reads it through the constant address space)
+template <class RG>
+__device__ __forceinline__ void xform(const RG &M, double x, double y, double z, double &ox, double &oy,
                                       double &oz) {
     ox = dadd(dadd(dadd(dmul(M.r[0], x), dmul(M.r[3], y)), dmul(M.r[6], z)), M.t[0]);
     oy = dadd(dadd(dadd(dmul(M.r[1], x), dmul(M.r[4], y)), dmul(M.r[7], z)), M.t[1]);
@@ -62,8 +64,8 @@ __device__ __forceinline__ void xform(const Rigid &M, double x, double y, double
 // Squared distance from the query to a candidate record.  XF: the record holds the point in the index's own frame
 // and is moved by the current (R,T) first -- CPointCloud::transform's expression, so the value is the one the
 // reference gets from its transformed copy, without that copy ever being written or read.
-template <bool XF>
-__device__ __forceinline__ double cand_d2(const Rigid *xf, double qx, double qy, double qz, const Pt4 &c) {
+template <bool XF, class RG = Rigid>
+__device__ __forceinline__ double cand_d2(const RG *xf, double qx, double qy, double qz, const Pt4 &c) {
     if constexpr (XF) {
         double x, y, z;
         xform(*xf, c.x, c.y, c.z, x, y, z);

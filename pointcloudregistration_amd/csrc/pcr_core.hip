@@ -1276,7 +1276,7 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
         if (M.levels == 1) {
             GridView &V = M.v[0];
             const uint64_t B_cells0 = ix->cells[0];
-            const double sc = 65536.0 / (sqrt(2.5) * V.h);
+            const double sc = (double)41448.97f / V.h;  // KEY_CELL (fast_search.h) root units per cell: 2.5 h^2 <-> 2^32 keys
             double ext = 0;
             for (int a = 0; a < 3; ++a) ext = fmax(ext, V.hi[a] - V.lo[a]);
             // per-axis error of a coordinate difference in root units: both operands rounded to fp32 (|Q| <= ext + 4h)
@@ -1292,6 +1292,8 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
                 V.key_S = sc * sc;
                 V.key_invS = 1.0 / V.key_S;
                 V.key_delta = (uint32_t)ceil(delta);
+                V.key_eps = (float)(4.0 * eps + 1.0);  // 2^-21 of the largest coordinate: a few fp32 roundings
+                for (int a = 0; a < 3; ++a) V.key_ext[a] = (float)((V.hi[a] - V.lo[a]) * sc * 1.000001);
             }
         }
         BUILD_HIP(hipStreamSynchronize(ctx->stream));

@@ -18,7 +18,7 @@
 #define PCR_STEP_WAVES 5
 #endif
 #ifndef PCR_FAST_WAVES
-#define PCR_FAST_WAVES 6
+#define PCR_FAST_WAVES 4
 #endif
 
 namespace pcr {
@@ -33,7 +33,10 @@ struct StepDyn {
     double pivot_p[3], pivot_q[3];
     double rev_bound_scale, rev_extra_margin;
     uint32_t done;  // device-resident loop only: converged/stopped -- the remaining enqueued kernels return at once
-    uint32_t pad;
+    // device-resident loop only: no source point's image moved farther than this since the previous iteration
+    // (+inf: unknown).  The K-th-neighbour distance is 1-Lipschitz in the query, so last iteration's distance plus this
+    // bounds this iteration's before a single candidate is looked at (StepArgs::dk_io).
+    float disp_bound;
 };
 
 // (R,T) -> everything else in StepDyn.  Host and device run this same code (bit-identical results).
@@ -56,11 +59,12 @@ PCR_HD inline bool make_dyn(const double *R, const double *T, const double *c_sr
     const double scale = fmax(fabs(T[0]) + fabs(T[1]) + fabs(T[2]), 0.0) + cloud_scale;
     D.rev_extra_margin = 3.637978807091713e-12 * scale;  // 2^-38: rounding of the inverse map
     D.done = 0;
-    D.pad = 0;
+    D.disp_bound = __builtin_huge_valf();
     return ok;
 }
 
 __global__ void set_dyn_kernel(StepDyn value, StepDyn *dst) { *dst = value; }
+
 
 __global__ void __launch_bounds__(256) transform_kernel(const Pt4 *__restrict__ in, uint32_t n,
                                                         const StepDyn *__restrict__ dyn, Pt4 *__restrict__ out) {
@@ -87,9 +91,40 @@ struct StepArgs {
     double thr_fwd, thr_rev;
     uint32_t exact;  // PCR_STEP_EXACT_INDICES
     double *block_partials;  // [17][gridDim.x]
+    // device-resident loop only (else NULL): per sample slot t, the forward search's exact K-th squared distance of the
+    // previous iteration, rounded up to float (+inf: none) -- read as a bound, overwritten with this iteration's
+    float *dk_io;
     uint32_t *out_fwd, *out_rev;
     uint8_t *out_keep;
 };
+
+// The filtered kernel reads its arguments from DEVICE memory (a copy of StepArgs), not from the kernel-argument
+// segment: by-value arguments are all fetched at kernel entry and stay live (or spilled) in scalar registers for the
+// whole kernel -- two grids' worth of geometry plus the transform is far more than the scalar file holds.  Behind a
+// pointer every phase loads what it needs where it needs it.
+__global__ void __launch_bounds__(256) set_args_kernel(StepArgs value, StepArgs *dst) {
+    const uint32_t *s = (const uint32_t *)&value;
+    uint32_t *d = (uint32_t *)dst;
+    for (uint32_t i = threadIdx.x; i < sizeof(StepArgs) / 4; i += 256) d[i] = s[i];
+}
+static_assert(sizeof(StepArgs) % 4 == 0 && sizeof(StepArgs) <= 3584, "StepArgs travels as a kernel argument of set_args_kernel");
+
+// An opaque copy of a (wave-uniform) pointer: loads through it cannot be merged with, or hoisted to, loads through
+// the original -- values are re-read where they are used instead of living in scalar registers across the searches.
+// The copy points into the CONSTANT address space: the memory is not written while the kernel runs (an earlier kernel
+// on the stream wrote it), and a load from there at a uniform address is a scalar load.
+#define PCR_CONST_AS __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ const PCR_CONST_AS T *reload_from(const T *p) {
+    const uint64_t v = (uint64_t)p;
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return (const PCR_CONST_AS T *)(((uint64_t)hi << 32) | lo);
+}
+template <class T>
+__device__ __forceinline__ const PCR_CONST_AS T *reload_from(const PCR_CONST_AS T *p) {
+    return reload_from((const T *)p);
+}
 
 // 17 per-lane values -> one value per block and column, stored column-major [17][nblocks] so that the fold
 // reads coalesced.  Wave reduction by shuffles, then LDS across the 4 waves.
@@ -114,8 +149,9 @@ __device__ __forceinline__ void block_reduce17(double (&v)[17], double *__restri
             (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
 
+template <class DY>
 __device__ __forceinline__ void accumulate(double (&acc)[17], bool keep, double px, double py, double pz, double qx,
-                                           double qy, double qz, double dF, const StepDyn &A) {
+                                           double qy, double qz, double dF, const DY &A) {
     const double ax = px - A.pivot_p[0], ay = py - A.pivot_p[1], az = pz - A.pivot_p[2];
     const double bx = qx - A.pivot_q[0], by = qy - A.pivot_q[1], bz = qz - A.pivot_q[2];
     const double w = keep ? 1.0 : 0.0;
@@ -247,106 +283,131 @@ __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(Step
 // from an isometry), and only the few candidates that reach the fp64 stage are moved by (R,T), with
 // CPointCloud::transform's expression.  Every index, flag and sum is bit-identical to icp_step_grid_kernel's (tested).
 template <int KC>
-__global__ void __launch_bounds__(256, PCR_FAST_WAVES) icp_step_fast_kernel(StepArgs A) {
-    const StepDyn *__restrict__ dynp = A.dyn;
-    if (dynp->done) return;  // uniform over the grid
-    const StepDyn D = *dynp;
+__global__ void __launch_bounds__(256, PCR_FAST_WAVES) icp_step_fast_kernel(const StepArgs *__restrict__ Ap) {
+    if (Ap->dyn->done) return;  // uniform over the grid
     const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t t = lb * 256u + threadIdx.x;
-    const bool live = t < A.m;
-    const GridView &GT = A.tgt.v[0], &GS = A.src.v[0];
-    uint32_t pos = 0, orig = 0, slot = 0;
-    double px = 0, py = 0, pz = 0;
-    if (live) {
-        if (A.sample_idx) {
-            orig = A.sample_idx[t];
-            pos = A.src_pos_of[orig];
-            slot = t;
-        } else {
-            pos = A.src_order[A.sample_begin + t];
-            orig = (uint32_t)A.src.all[pos].w;
-            slot = orig;
-        }
-        const Pt4 s = A.src.all[pos];
-        xform(D.M, s.x, s.y, s.z, px, py, pz);  // CurSrcPoint = R*s + T (:86)
-    }
     __shared__ uint2 rowtab[9][256];
     uint2 *my_rows = &rowtab[0][threadIdx.x];
-    // ---- forward: K-th nearest target point of p (:89-92)
-    const double fmax_d2 = A.exact ? PCR_INF : A.thr_fwd;
-    const double fwd_scale = 1.0 - 1.8189894035458565e-12;
-    const bool fin = live && isfinite(px) && isfinite(py) && isfinite(pz);
-    TopK<KC> top;
-    top.init(fmax_d2);
-    bool fwd_done = !fin;
-    if (fin)
-        fwd_done = fast_ring1<KC, false>(GT, GT.pts, px, py, pz, px, py, pz, fmax_d2, PCR_INF, fwd_scale, 0.0, GT.key_delta,
-                                         A.k, top, my_rows, nullptr);
-    if (__any(!fwd_done)) {
-        if (!fwd_done) {
-            top.init(fmax_d2);
-            lane_search<KC>(GT, A.tgt.all, px, py, pz, px, py, pz, fmax_d2, fwd_scale, 0.0, top, my_rows);
+    uint32_t pos = 0, orig = 0, slot = 0;
+    double px = 0, py = 0, pz = 0;
+    bool live;
+    {
+        const PCR_CONST_AS StepArgs *A = reload_from(Ap);
+        live = t < A->m;
+        if (live) {
+            if (A->sample_idx) {
+                orig = A->sample_idx[t];
+                pos = A->src_pos_of[orig];
+                slot = t;
+            } else {
+                pos = A->src_order[A->sample_begin + t];
+                orig = (uint32_t)A->src.all[pos].w;
+                slot = orig;
+            }
+            const Pt4 s = A->src.all[pos];
+            xform(reload_from(A->dyn)->M, s.x, s.y, s.z, px, py, pz);  // CurSrcPoint = R*s + T (:86)
         }
     }
+    // ---- forward: K-th nearest target point of p (:89-92)
+    const bool fin = live && isfinite(px) && isfinite(py) && isfinite(pz);
     double dF;
     uint32_t j;
-    top.slot(A.k, dF, j);  // NeighborSet.back() = K-th nearest (:91-92)
-    const bool found = fin && j != PCR_NO_INDEX && dF < fmax_d2;
-    const bool passF = found && dF < A.thr_fwd;  // strict < (:97)
-
-    // ---- reverse: nearest TRANSFORMED source point of q (:94-95), seeded with the sample's own image (distance dF)
-    const bool need_rev = found && (passF || A.exact);
-    double qx = 0, qy = 0, qz = 0, sx = 0, sy = 0, sz = 0;
-    if (need_rev) {
-        const Pt4 qpt = A.tgt.all[A.tgt.pos_of[j]];
-        qx = qpt.x;
-        qy = qpt.y;
-        qz = qpt.z;
-        const double ux = qx - D.M.t[0], uy = qy - D.M.t[1], uz = qz - D.M.t[2];
-        sx = D.rinv[0] * ux + D.rinv[3] * uy + D.rinv[6] * uz;
-        sy = D.rinv[1] * ux + D.rinv[4] * uy + D.rinv[7] * uz;
-        sz = D.rinv[2] * ux + D.rinv[5] * uy + D.rinv[8] * uz;
-    }
-    TopK<1> rt;
-    rt.d[0] = dF;
-    rt.idx[0] = orig;
-    const bool rev_active = need_rev && isfinite(sx) && isfinite(sy) && isfinite(sz);
-    // key error of the reverse search: the source grid's own, plus |R v|^2 vs |v|^2 (1 - rev_bound_scale >= 3 * the
-    // orthogonality defect) over the key range, plus the rounding of the inverse map at the largest distance of interest
-    const uint32_t rev_delta =
-        GS.key_delta + (uint32_t)fmin((1.0 - D.rev_bound_scale) * 1.1 * 4294967296.0 +
-                                          2.0 * 65536.0 * 1.01 * D.rev_extra_margin * GS.key_sc + 2.0,
-                                      1073741824.0);
-    bool rev_done = !rev_active;
-    if (rev_active)
-        rev_done = fast_ring1<1, true>(GS, GS.pts, qx, qy, qz, sx, sy, sz, PCR_INF, dF, D.rev_bound_scale, D.rev_extra_margin,
-                                       rev_delta, 1, rt, my_rows, &D.M);
-    if (__any(!rev_done)) {
-        if (!rev_done) {
-            rt.d[0] = dF;
-            rt.idx[0] = orig;
-            lane_search<1, true>(GS, A.src.all, qx, qy, qz, sx, sy, sz, PCR_INF, D.rev_bound_scale, D.rev_extra_margin, rt,
-                                 my_rows, &D.M);
+    bool found, passF, need_rev;
+    {
+        const PCR_CONST_AS StepArgs *A = reload_from(Ap);
+        const PCR_CONST_AS GridView &GT = A->tgt.v[0];
+        const double fmax_d2 = A->exact ? PCR_INF : A->thr_fwd;
+        const double fwd_scale = 1.0 - 1.8189894035458565e-12;
+        bool fwd_done = !fin;
+        dF = fmax_d2;
+        j = PCR_NO_INDEX;
+        // what last iteration knew: its K-th distance, and how far a point can have moved since (both rounded up)
+        double bound_d2 = PCR_INF;
+        float *dk_io = A->dk_io;
+        if (dk_io && live) {
+            const float a = sqrtf(dk_io[t]) * 1.0000005f, b = reload_from(A->dyn)->disp_bound;
+            const float s2 = (a + b) * 1.0000005f;
+            bound_d2 = (double)(s2 * s2) * 1.000001;  // inf stays inf
         }
+        if (fin)  // NeighborSet.back() = K-th nearest (:91-92)
+            fwd_done = fast_ring1<KC, false, false>(GT, GT.pts, px, py, pz, px, py, pz, fmax_d2, bound_d2, fwd_scale, 0.0,
+                                                    GT.key_delta, A->k, 0.0, 0u, dF, j, my_rows, (const Rigid *)nullptr);
+        if (__any(!fwd_done)) {
+            if (!fwd_done) {
+                TopK<KC> top;
+                top.init(fmax_d2);
+                const GridView G = Ap->tgt.v[0];  // (the rare path: through the generic pointer)
+                lane_search<KC>(G, Ap->tgt.all, px, py, pz, px, py, pz, fmax_d2, fwd_scale, 0.0, top, my_rows);
+                top.slot(A->k, dF, j);
+            }
+        }
+        found = fin && j != PCR_NO_INDEX && dF < fmax_d2;
+        passF = found && dF < A->thr_fwd;  // strict < (:97)
+        need_rev = found && (passF || A->exact);
+        if (dk_io && live) dk_io[t] = found ? __double2float_ru(dF) : __builtin_huge_valf();
     }
+    // ---- reverse: nearest TRANSFORMED source point of q (:94-95), seeded with the sample's own image (distance dF)
+    double qx = 0, qy = 0, qz = 0;
     uint32_t r = PCR_NO_INDEX;
     bool keep = false;
-    if (need_rev) {
-        r = rt.idx[0];
-        const Pt4 sp = A.src.all[r == orig ? pos : A.src_pos_of[r]];
-        const double dR = cand_d2<true>(&D.M, px, py, pz, sp);  // (CurSrcPoint - TmpPoint).squaredNorm()
-        keep = passF && dR < A.thr_rev;                          // strict < (:98)
+    {
+        const PCR_CONST_AS StepArgs *A = reload_from(Ap);
+        const PCR_CONST_AS StepDyn *D = reload_from(A->dyn);
+        const PCR_CONST_AS GridView &GS = A->src.v[0];
+        double sx = 0, sy = 0, sz = 0;
+        if (need_rev) {
+            const Pt4 qpt = A->tgt.all[A->tgt.pos_of[j]];
+            qx = qpt.x;
+            qy = qpt.y;
+            qz = qpt.z;
+            const double ux = qx - D->M.t[0], uy = qy - D->M.t[1], uz = qz - D->M.t[2];
+            sx = D->rinv[0] * ux + D->rinv[3] * uy + D->rinv[6] * uz;
+            sy = D->rinv[1] * ux + D->rinv[4] * uy + D->rinv[7] * uz;
+            sz = D->rinv[2] * ux + D->rinv[5] * uy + D->rinv[8] * uz;
+        }
+        const bool rev_active = need_rev && isfinite(sx) && isfinite(sy) && isfinite(sz);
+        // key error of the reverse search: the source grid's own, plus |R v|^2 vs |v|^2 (1 - rev_bound_scale >= 3 * the
+        // orthogonality defect) over the key range, plus the rounding of the inverse map at the largest distance of interest
+        const double rbs = D->rev_bound_scale, rem_ = D->rev_extra_margin;
+        const uint32_t rev_delta =
+            GS.key_delta + (uint32_t)fmin((1.0 - rbs) * 1.1 * 4294967296.0 + 2.0 * 65536.0 * 1.01 * rem_ * GS.key_sc + 2.0,
+                                          1073741824.0);
+        bool rev_done = !rev_active;
+        double dRv = dF;  // the reverse winner's distance to q (not used further) and index
+        uint32_t rv = orig;
+        if (rev_active)
+            rev_done = fast_ring1<1, true, true>(GS, GS.pts, qx, qy, qz, sx, sy, sz, PCR_INF, dF, rbs, rem_, rev_delta, 1, dF,
+                                                 orig, dRv, rv, my_rows, &D->M);
+        if (__any(!rev_done)) {
+            if (!rev_done) {
+                TopK<1> rt;
+                rt.d[0] = dF;
+                rt.idx[0] = orig;
+                const GridView G = Ap->src.v[0];
+                const Rigid M = Ap->dyn->M;
+                lane_search<1, true>(G, Ap->src.all, qx, qy, qz, sx, sy, sz, PCR_INF, rbs, rem_, rt, my_rows, &M);
+                rv = rt.idx[0];
+            }
+        }
+        if (need_rev) {
+            r = rv;
+            const Pt4 sp = A->src.all[r == orig ? pos : A->src_pos_of[r]];
+            const double dR = cand_d2<true>(&D->M, px, py, pz, sp);  // (CurSrcPoint - TmpPoint).squaredNorm()
+            keep = passF && dR < A->thr_rev;                          // strict < (:98)
+        }
     }
+    const PCR_CONST_AS StepArgs *A = reload_from(Ap);
     double acc[17];
 #pragma unroll
     for (int i = 0; i < 17; ++i) acc[i] = 0.0;
     if (live) {
-        accumulate(acc, keep, px, py, pz, qx, qy, qz, dF, D);
-        if (A.out_fwd) A.out_fwd[slot] = found ? j : PCR_NO_INDEX;
-        if (A.out_rev) A.out_rev[slot] = r;
-        if (A.out_keep) A.out_keep[slot] = keep ? 1 : 0;
+        accumulate(acc, keep, px, py, pz, qx, qy, qz, dF, *reload_from(A->dyn));
+        if (A->out_fwd) A->out_fwd[slot] = found ? j : PCR_NO_INDEX;
+        if (A->out_rev) A->out_rev[slot] = r;
+        if (A->out_keep) A->out_keep[slot] = keep ? 1 : 0;
     }
-    block_reduce17(acc, A.block_partials, lb, gridDim.x);
+    block_reduce17(acc, A->block_partials, lb, gridDim.x);
 }
 
 // Small clouds: both searches as tiled brute force (LDS-staged tiles, broadcast reads).
@@ -476,6 +537,7 @@ static void cloud_centre(const pcr_cloud *c, double out[3]) {
 struct FitDev {
     StepDyn dyn;  // first member: the step kernels read it through a StepDyn pointer
     double c_src[3], c_tgt[3], cloud_scale;
+    double src_rad;  // half the diagonal of the source's bounds: no source point is farther from c_src
     double uniq;  // CUniqueData of the target: scales the MSE thresholds
     pcr_convergence_params conv;
     int32_t conv_enabled;
@@ -581,6 +643,17 @@ __global__ void fit_solve_kernel(FitDev *F, const double *__restrict__ partials,
         converged = true;
     }
     next.done = converged ? 1u : 0u;
+    {
+        // |p_new - p_old| = |dR (s - c) + (dR c + dT)| <= |dR|_F * rad + |dR c + dT| for every source point s
+        double fro = 0, v[3];
+        for (int i = 0; i < 9; ++i) fro += (R[i] - F->dyn.M.r[i]) * (R[i] - F->dyn.M.r[i]);
+        for (int r = 0; r < 3; ++r)
+            v[r] = (R[r] - F->dyn.M.r[r]) * F->c_src[0] + (R[3 + r] - F->dyn.M.r[3 + r]) * F->c_src[1] +
+                   (R[6 + r] - F->dyn.M.r[6 + r]) * F->c_src[2] + (T[r] - F->dyn.M.t[r]);
+        const double disp = sqrt(fro) * F->src_rad + sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        // slack: the roundings of both evaluations of R*s + T, and of this bound itself
+        next.disp_bound = __double2float_ru(disp * 1.000001 + 1e-12 * (F->cloud_scale + fabs(T[0]) + fabs(T[1]) + fabs(T[2])));
+    }
     F->dyn = next;
 }
 
@@ -599,11 +672,14 @@ struct pcr_fit {
     double *block_partials_d;
     double *traj_d;       // [traj_cap][14]
     uint32_t *samples_d;  // owned copy of a host sample list (pcr_fit_set_samples)
+    StepArgs *args_d;     // device copy of args (what the filtered kernel reads)
+    float *dk_d;          // [m] StepArgs::dk_io
     FitDev init;          // host-side template of the state (reset copies it)
 };
 
+// args_d: a device copy of A (set_args_kernel), what the filtered kernel reads its arguments from
 static void launch_step_kernels(pcr_ctx *ctx, const pcr_index *src, const StepArgs &A, uint32_t nb, uint32_t k,
-                                double *partials_d) {
+                                double *partials_d, const StepArgs *args_d) {
     // CPointCloud::transform of the whole source (:73-74): the grid kernels do it candidate by candidate as they
     // search; a materialised copy (in index order) is only made for the brute-force kernel, or on request (tune 4)
     // Which is cheaper depends on how many samples this launch serves: the copy costs ~11 us per million SOURCE points
@@ -612,14 +688,14 @@ static void launch_step_kernels(pcr_ctx *ctx, const pcr_index *src, const StepAr
     // tune 4: 0 = by this rule, 1 = always copy, 2 = always on the fly.
     // single-level grids with fp32 shadows and K <= 4: the filtered kernel (tune 5: 1 = never, for A/B runs and tests)
     const bool fast = src->kind == PCR_INDEX_GRID && g_tune[5] != 1 && k <= 4 && A.src.levels == 1 && A.tgt.levels == 1 &&
-                      A.src.v[0].shadow && A.tgt.v[0].shadow;
+                      A.src.v[0].shadow && A.tgt.v[0].shadow && args_d;
     if (fast) {
         {
             ProfScope ps(ctx, PCR_PROF_STEP);
             if (k == 1)
-                hipLaunchKernelGGL(icp_step_fast_kernel<1>, dim3(nb), dim3(256), 0, ctx->stream, A);
+                hipLaunchKernelGGL(icp_step_fast_kernel<1>, dim3(nb), dim3(256), 0, ctx->stream, args_d);
             else
-                hipLaunchKernelGGL(icp_step_fast_kernel<4>, dim3(nb), dim3(256), 0, ctx->stream, A);
+                hipLaunchKernelGGL(icp_step_fast_kernel<4>, dim3(nb), dim3(256), 0, ctx->stream, args_d);
         }
         ProfScope ps(ctx, PCR_PROF_FOLD);
         hipLaunchKernelGGL(fold_partials_kernel, dim3(17), dim3(256), 0, ctx->stream, (const double *)A.block_partials, nb,
@@ -713,13 +789,19 @@ int pcr_icp_pivots(const pcr_index *src, const pcr_index *tgt, const double R[9]
     return PCR_OK;
 }
 
+// device-side scratch of one step besides the block partials
+struct StepScratch {
+    StepDyn dyn;
+    StepArgs args;
+};
+
 // What pcr_icp_step_d and pcr_icp_step_noalloc_d share: argument checks, the per-iteration constants, the launches.
 // dyn_d and block_partials_d are the step's scratch (device memory beyond inputs and outputs); who owns them is the
 // only difference between the two entry points.
 static int step_enqueue(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const uint32_t *sample_idx_d,
                         uint32_t sample_begin, uint32_t m, const double R[9], const double T[3], uint32_t k,
                         double thr_fwd_sq, double thr_rev_sq, uint32_t flags, double *partials_d, uint32_t *out_fwd_d,
-                        uint32_t *out_rev_d, uint8_t *out_keep_d, StepDyn *dyn_d, double *block_partials_d,
+                        uint32_t *out_rev_d, uint8_t *out_keep_d, StepScratch *sc_d, double *block_partials_d,
                         const char *who) {
     StepArgs A;
     int rc = prepare_step_args(ctx, src, tgt, sample_idx_d, sample_begin, m, k, thr_fwd_sq, thr_rev_sq, flags, A, who);
@@ -741,10 +823,11 @@ static int step_enqueue(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt
         return PCR_OK;
     }
     A.block_partials = block_partials_d;
-    A.dyn = dyn_d;
-    // the per-iteration values travel as a kernel argument of a one-thread kernel: stream-ordered, no staging buffer
-    hipLaunchKernelGGL(set_dyn_kernel, dim3(1), dim3(1), 0, ctx->stream, D, dyn_d);
-    launch_step_kernels(ctx, src, A, nb, k, partials_d);
+    A.dyn = &sc_d->dyn;
+    // the per-iteration values and the arguments travel as kernel arguments of tiny kernels: stream-ordered, no staging
+    hipLaunchKernelGGL(set_dyn_kernel, dim3(1), dim3(1), 0, ctx->stream, D, &sc_d->dyn);
+    hipLaunchKernelGGL(set_args_kernel, dim3(1), dim3(256), 0, ctx->stream, A, &sc_d->args);
+    launch_step_kernels(ctx, src, A, nb, k, partials_d, &sc_d->args);
     PCR_HIP(hipGetLastError());
     return PCR_OK;
 }
@@ -766,7 +849,7 @@ int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
         PCR_HIP(hipMalloc(&ctx->block_partials_d, sizeof(double) * 17 * (size_t)nb));
         ctx->block_partials_cap = (size_t)nb * 17;
     }
-    StepDyn *dyn_d = (StepDyn *)ctx_scratch(ctx, 5, sizeof(StepDyn));
+    StepScratch *dyn_d = (StepScratch *)ctx_scratch(ctx, 5, sizeof(StepScratch));
     if (!dyn_d) return PCR_E_NOMEM;
     return step_enqueue(ctx, src, tgt, sample_idx_d, sample_begin, m, R, T, k, thr_fwd_sq, thr_rev_sq, flags, partials_d,
                         out_fwd_d, out_rev_d, out_keep_d, dyn_d, ctx->block_partials_d, "pcr_icp_step_d");
@@ -779,7 +862,7 @@ int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
 // current) and only that pointer is ever handed to a kernel.  Every GPU the library runs on holds its own copy until
 // the process ends.
 struct NoAllocScratch {
-    StepDyn dyn;
+    StepScratch step;
     double block_partials[17 * (size_t)(PCR_NOALLOC_MAX_SAMPLES / 256u)];
 };
 static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocScratch)];
@@ -812,7 +895,7 @@ int pcr_icp_step_noalloc_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *
     PCR_REQUIRE(S, "pcr_icp_step_noalloc_d: no scratch on device %d (set up by pcr_ctx_create)", ctx->device);
     PCR_HIP(hipSetDevice(ctx->device));
     return step_enqueue(ctx, src, tgt, sample_idx_d, sample_begin, m, R, T, k, thr_fwd_sq, thr_rev_sq, flags, partials_d,
-                        out_fwd_d, out_rev_d, out_keep_d, &S->dyn, S->block_partials, "pcr_icp_step_noalloc_d");
+                        out_fwd_d, out_rev_d, out_keep_d, &S->step, S->block_partials, "pcr_icp_step_noalloc_d");
 }
 
 int pcr_icp_step(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const uint32_t *sample_idx, uint32_t m,
@@ -909,6 +992,8 @@ int pcr_fit_destroy(pcr_fit *f) {
     if (f->block_partials_d) hipFree(f->block_partials_d);
     if (f->traj_d) hipFree(f->traj_d);
     if (f->samples_d) hipFree(f->samples_d);
+    if (f->args_d) hipFree(f->args_d);
+    if (f->dk_d) hipFree(f->dk_d);
     delete f;
     return PCR_OK;
 }
@@ -937,6 +1022,11 @@ int pcr_fit_create(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
     cloud_centre(src->cloud, I.c_src);
     cloud_centre(tgt->cloud, I.c_tgt);
     I.cloud_scale = clouds_scale(src->cloud, tgt->cloud);
+    {
+        double d2 = 0;
+        for (int a = 0; a < 3; ++a) d2 += (src->cloud->hi[a] - src->cloud->lo[a]) * (src->cloud->hi[a] - src->cloud->lo[a]);
+        I.src_rad = 0.5 * sqrt(d2) * (1.0 + 1e-12);
+    }
     I.uniq = unique_sq_dist;
     if (conv) {
         I.conv = *conv;
@@ -948,6 +1038,8 @@ int pcr_fit_create(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
     if (e == hipSuccess) e = hipMalloc(&f->partials_d, sizeof(double) * 32);
     if (e == hipSuccess) e = hipMalloc(&f->block_partials_d, sizeof(double) * 17 * (size_t)(f->nb ? f->nb : 1));
     if (e == hipSuccess && traj_cap) e = hipMalloc(&f->traj_d, sizeof(double) * 14 * (size_t)traj_cap);
+    if (e == hipSuccess) e = hipMalloc(&f->args_d, sizeof(StepArgs));
+    if (e == hipSuccess && m) e = hipMalloc(&f->dk_d, sizeof(float) * (size_t)m);
     if (e != hipSuccess) {
         set_last_error("pcr_fit_create: allocation failed: %s", hipGetErrorString(e));
         pcr_fit_destroy(f);
@@ -955,6 +1047,8 @@ int pcr_fit_create(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
     }
     f->args.dyn = &f->dev_d->dyn;
     f->args.block_partials = f->block_partials_d;
+    f->args.dk_io = f->dk_d;
+    hipLaunchKernelGGL(set_args_kernel, dim3(1), dim3(256), 0, ctx->stream, f->args, f->args_d);
     const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, zero[3] = {0, 0, 0};
     rc = pcr_fit_reset(f, eye, zero);
     if (rc != PCR_OK) {
@@ -980,14 +1074,21 @@ int pcr_fit_set_samples(pcr_fit *f, const uint32_t *sample_idx, uint32_t m) {
         PCR_HIP(hipMalloc(&f->block_partials_d, sizeof(double) * 17 * (size_t)nb));
         f->args.block_partials = f->block_partials_d;
     }
+    if (f->dk_d) hipFree(f->dk_d);
+    f->dk_d = nullptr;
     if (m) {
         PCR_HIP(hipMalloc(&f->samples_d, sizeof(uint32_t) * (size_t)m));
         PCR_HIP(hipMemcpy(f->samples_d, sample_idx, sizeof(uint32_t) * (size_t)m, hipMemcpyHostToDevice));
+        PCR_HIP(hipMalloc(&f->dk_d, sizeof(float) * (size_t)m));
+        PCR_HIP(hipMemsetD32Async((hipDeviceptr_t)f->dk_d, 0x7f800000, m, f->ctx->stream));  // +inf: nothing known
     }
+    f->args.dk_io = f->dk_d;
     f->args.sample_idx = f->samples_d;
     f->args.sample_begin = 0;
     f->args.m = m;
     f->nb = nb;
+    hipLaunchKernelGGL(set_args_kernel, dim3(1), dim3(256), 0, f->ctx->stream, f->args, f->args_d);
+    PCR_HIP(hipGetLastError());
     return PCR_OK;
 }
 
@@ -1008,6 +1109,8 @@ int pcr_fit_reset(pcr_fit *f, const double R[9], const double T[3]) {
     I.similar = 0;
     I.iteration = 0;
     I.state = PCR_FIT_NOT_CONVERGED;
+    if (f->dk_d)  // +inf: the first iteration knows nothing about its neighbour distances
+        PCR_HIP(hipMemsetD32Async((hipDeviceptr_t)f->dk_d, 0x7f800000, f->args.m, f->ctx->stream));
     hipLaunchKernelGGL(fit_init_kernel, dim3(1), dim3(1), 0, f->ctx->stream, I, f->dev_d);
     PCR_HIP(hipGetLastError());
     return PCR_OK;
@@ -1020,7 +1123,7 @@ int pcr_fit_enqueue_step(pcr_fit *f) {
         PCR_HIP(hipMemsetAsync(f->partials_d, 0, sizeof(double) * 17, f->ctx->stream));
         return PCR_OK;
     }
-    launch_step_kernels(f->ctx, f->src, f->args, f->nb, f->kc, f->partials_d);
+    launch_step_kernels(f->ctx, f->src, f->args, f->nb, f->kc, f->partials_d, f->args_d);
     PCR_HIP(hipGetLastError());
     return PCR_OK;
 }

@@ -62,6 +62,8 @@ struct GridView {
     const float4 *shadow;
     double key_sc, key_S, key_invS;  // key = key_S * d2, key_S = key_sc^2
     uint32_t key_delta;
+    float key_eps;                   // what every fp32 gap of the walk's geometry is shrunk by, in root units
+    float key_ext[3];                // (hi - lo) * key_sc, rounded up
 };
 
 // An index is a small stack of such grids over DISJOINT subsets of the cloud ("levels"): level 0 spans the whole
