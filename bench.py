@@ -175,6 +175,9 @@ def main():
 
     def enqueue(steps):
         for _ in range(steps):
+            if not (world > 1 or force_dist):
+                fit.iterate()  # one launch: the step kernel's last block folds and solves
+                continue
             fit.step()
             if world > 1 or force_dist:
                 if rehearse:

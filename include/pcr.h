@@ -277,6 +277,9 @@ int pcr_fit_reset(pcr_fit *fit, const double R[9], const double T[3]);
 int pcr_fit_enqueue_step(pcr_fit *fit);
 double *pcr_fit_partials_d(pcr_fit *fit);
 int pcr_fit_enqueue_solve(pcr_fit *fit);
+/* pcr_fit_enqueue_step + pcr_fit_enqueue_solve for a fit that needs no exchange in between (one GPU): where the step
+ * runs as the filtered kernel, its last block folds the partials and runs the solve -- ONE launch per iteration. */
+int pcr_fit_enqueue_iteration(pcr_fit *fit);
 /* synchronises the stream.  All outputs nullable; traj receives min(iterations, traj_cap, traj_rows) rows. */
 int pcr_fit_read(pcr_fit *fit, double R[9], double T[3], uint32_t *iterations, int *state, double *mse,
                  double *pairs, double *traj, uint32_t traj_rows);

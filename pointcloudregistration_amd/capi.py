@@ -84,6 +84,7 @@ SYMBOLS = {
     "pcr_fit_enqueue_step": (C.c_int, [_vp]),
     "pcr_fit_partials_d": (_vp, [_vp]),
     "pcr_fit_enqueue_solve": (C.c_int, [_vp]),
+    "pcr_fit_enqueue_iteration": (C.c_int, [_vp]),
     "pcr_fit_read": (C.c_int, [_vp, _dp, _dp, _up, C.POINTER(C.c_int), _dp, _dp, _dp, C.c_uint32]),
     "pcr_fit_destroy": (C.c_int, [_vp]),
     "pcr_comm_unique_id": (C.c_int, [C.c_char_p]),
@@ -373,6 +374,10 @@ class Fit:
     def solve(self):
         _check(lib().pcr_fit_enqueue_solve(self.h), "pcr_fit_enqueue_solve")
 
+    def iterate(self):
+        """step + solve with nothing in between: one launch per iteration where the filtered kernel applies."""
+        _check(lib().pcr_fit_enqueue_iteration(self.h), "pcr_fit_enqueue_iteration")
+
     def partials_tensor(self):
         """The 17 partial sums as a torch view of the fit's device buffer (for torch.distributed.all_reduce)."""
         import torch
@@ -397,9 +402,11 @@ class Fit:
         self.reset(R, T)
         part = self.partials_tensor() if all_reduce is not None else None
         for _ in range(max_steps):
+            if all_reduce is None:
+                self.iterate()
+                continue
             self.step()
-            if all_reduce is not None:
-                all_reduce(part)
+            all_reduce(part)
             self.solve()
         return self.read()
 

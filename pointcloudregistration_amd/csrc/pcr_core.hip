@@ -447,6 +447,8 @@ void *ctx_scratch(pcr_ctx *ctx, int slot, size_t bytes) {
         return nullptr;
     }
     ctx->scratch_cap[slot] = want;
+    // new scratch starts zeroed (the in-kernel fold's counters rely on it; nothing else minds)
+    (void)hipMemsetAsync(ctx->scratch_d[slot], 0, want, ctx->stream);
     return ctx->scratch_d[slot];
 }
 

@@ -79,6 +79,7 @@ __global__ void __launch_bounds__(256) transform_kernel(const Pt4 *__restrict__ 
     }
 }
 
+struct FitDev;
 struct StepArgs {
     MultiView src, tgt;
     const Pt4 *tsrc;             // transformed source, parallel to src.pts
@@ -94,6 +95,15 @@ struct StepArgs {
     // device-resident loop only (else NULL): per sample slot t, the forward search's exact K-th squared distance of the
     // previous iteration, rounded up to float (+inf: none) -- read as a bound, overwritten with this iteration's
     float *dk_io;
+    // In-kernel fold (filtered kernel; NULL tickets: fold_partials_kernel follows instead).  Blocks are grouped by 64;
+    // the block that finishes a group last folds the group's partials, the block that finishes the last group folds
+    // the groups into partials_out -- fixed grouping, fixed order: bitwise reproducible -- and sets every counter back
+    // to zero for the next launch.  fit_inline (device-resident loop on one GPU): that same block then runs the solve.
+    uint32_t *tickets;       // [1 + ngroups], zero between launches
+    double *group_partials;  // [17][ngroups]
+    double *partials_out;    // [17]
+    struct FitDev *fit_inline;
+    double *fit_traj;
     uint32_t *out_fwd, *out_rev;
     uint8_t *out_keep;
 };
@@ -126,6 +136,16 @@ __device__ __forceinline__ const PCR_CONST_AS T *reload_from(const PCR_CONST_AS 
     return reload_from((const T *)p);
 }
 
+// Relaxed atomics at DEVICE scope: performed at the memory side, past the per-XCD L2s.  Data that blocks hand to each
+// other inside one kernel travels through these; a device-scope release FENCE instead would write the whole L2 back
+// (measured: one per block doubles the step kernel's time).
+__device__ __forceinline__ void st_agent(double *p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // 17 per-lane values -> one value per block and column, stored column-major [17][nblocks] so that the fold
 // reads coalesced.  Wave reduction by shuffles, then LDS across the 4 waves.
 __device__ __forceinline__ void block_reduce17(double (&v)[17], double *__restrict__ out, uint32_t block,
@@ -144,9 +164,10 @@ __device__ __forceinline__ void block_reduce17(double (&v)[17], double *__restri
         for (int j = 0; j < 17; ++j) sm[wave][j] = v[j];
     }
     __syncthreads();
+    // a device-scope (write-through) store: the in-kernel fold of another block, on another XCD, reads it
     if (threadIdx.x < 17)
-        out[(size_t)threadIdx.x * nblocks + block] =
-            (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+        st_agent(&out[(size_t)threadIdx.x * nblocks + block],
+                 (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]));
 }
 
 template <class DY>
@@ -172,6 +193,56 @@ __device__ __forceinline__ void accumulate(double (&acc)[17], bool keep, double 
     acc[14] = keep ? az * by : 0.0;
     acc[15] = keep ? az * bz : 0.0;
     acc[16] = keep ? dF : 0.0;
+}
+
+// one thread of the solve (defined with the device-resident loop below)
+__device__ void fit_solve_body(FitDev *F, const double *partials, double *traj);
+
+// 17 columns x `count` values (column j at x + j * stride) -> out[j * out_stride]: eight threads per column, each a
+// fixed strided share, then a fixed shuffle tree.  Called by whole blocks; threads 0..135 work.
+__device__ __forceinline__ void fold17(const double *x, size_t stride, uint32_t count, double *out, size_t out_stride) {
+    const uint32_t tid = threadIdx.x, col = tid >> 3, sub = tid & 7u;
+    double s = 0.0;
+    if (tid < 136u)
+        for (uint32_t i = sub; i < count; i += 8u) s += ld_agent(&x[(size_t)col * stride + i]);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 1, 64);
+    if (tid < 136u && sub == 0u) st_agent(&out[(size_t)col * out_stride], s);
+}
+
+// After block_reduce17: the in-kernel fold described at StepArgs::tickets.  Block-uniform control flow throughout.
+template <class AP>
+__device__ __forceinline__ void fold_in_kernel(AP A, uint32_t lb, uint32_t nb) {
+    uint32_t *tickets = A->tickets;
+    if (!tickets) return;
+    __shared__ uint32_t s_last;
+    const uint32_t ngroups = (nb + 63u) >> 6, g = lb >> 6;
+    // The block's partials are device-scope stores by its threads 0..16; the barrier (which waits for them to
+    // complete) orders them before thread 0's ticket, a device-scope atomic.  The block that draws the last ticket of a
+    // group therefore reads complete partials (device-scope loads) -- no fence anywhere.
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(&tickets[1u + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                         min(64u, nb - (g << 6)) - 1u
+                     ? 1u
+                     : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    fold17(A->block_partials + ((size_t)g << 6), nb, min(64u, nb - (g << 6)), A->group_partials + g, ngroups);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(&tickets[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1u ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    double *out = A->partials_out;
+    fold17(A->group_partials, ngroups, ngroups, out, 1);
+    for (uint32_t i = threadIdx.x; i < ngroups + 1u; i += 256u) tickets[i] = 0u;
+    FitDev *fit = A->fit_inline;
+    if (fit) {
+        __syncthreads();
+        if (threadIdx.x == 0) fit_solve_body(fit, out, A->fit_traj);
+    }
 }
 
 // MULTI: either index has more than one level (clouds of very uneven density); the single-level instance is the
@@ -274,6 +345,7 @@ __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(Step
         if (A.out_keep) A.out_keep[slot] = keep ? 1 : 0;
     }
     block_reduce17(acc, A.block_partials, lb, gridDim.x);
+    fold_in_kernel(&A, lb, gridDim.x);
 }
 
 // The same iteration on single-level grids that carry fp32 shadows: both searches go through the filtered walk
@@ -408,6 +480,7 @@ __global__ void __launch_bounds__(256, PCR_FAST_WAVES) icp_step_fast_kernel(cons
         if (A->out_keep) A->out_keep[slot] = keep ? 1 : 0;
     }
     block_reduce17(acc, A->block_partials, lb, gridDim.x);
+    fold_in_kernel(A, lb, gridDim.x);
 }
 
 // Small clouds: both searches as tiled brute force (LDS-staged tiles, broadcast reads).
@@ -484,6 +557,7 @@ __global__ void __launch_bounds__(256) icp_step_brute_kernel(StepArgs A) {
         if (A.out_keep) A.out_keep[slot] = keep ? 1 : 0;
     }
     block_reduce17(acc, A.block_partials, blockIdx.x, gridDim.x);
+    fold_in_kernel(&A, blockIdx.x, gridDim.x);
 }
 
 // Fold the block partials in a fixed order: block j of the grid owns column j (one of the 17 sums); its 256
@@ -556,8 +630,7 @@ __global__ void fit_init_kernel(FitDev value, FitDev *dst) { *dst = value; }
 
 // One thread: what CIterativeFit::_fitStepV does after the correspondences (IterativeFit.cpp:156-174) --
 // computeRotationAndTranslation, then the convergence criteria -- followed by the preparation of the next step.
-__global__ void fit_solve_kernel(FitDev *F, const double *__restrict__ partials, double *__restrict__ traj) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __noinline__ void fit_solve_body(FitDev *F, const double *partials, double *traj) {
     if (F->dyn.done) return;
     double part[17];
     for (int i = 0; i < 17; ++i) part[i] = partials[i];
@@ -657,6 +730,10 @@ __global__ void fit_solve_kernel(FitDev *F, const double *__restrict__ partials,
     F->dyn = next;
 }
 
+__global__ void fit_solve_kernel(FitDev *F, const double *__restrict__ partials, double *__restrict__ traj) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) fit_solve_body(F, partials, traj);
+}
+
 }  // namespace pcr
 
 using namespace pcr;
@@ -672,13 +749,42 @@ struct pcr_fit {
     double *block_partials_d;
     double *traj_d;       // [traj_cap][14]
     uint32_t *samples_d;  // owned copy of a host sample list (pcr_fit_set_samples)
-    StepArgs *args_d;     // device copy of args (what the filtered kernel reads)
+    StepArgs *args_d;     // [2] device copies of args (what the filtered kernel reads): [1] also solves in the kernel
+    double *group_partials_d;
+    uint32_t *tickets_d;
     float *dk_d;          // [m] StepArgs::dk_io
     FitDev init;          // host-side template of the state (reset copies it)
 };
 
+// (re)allocates the in-kernel fold's scratch for f->nb blocks; tickets start at zero and every launch leaves them so
+static hipError_t fit_alloc_fold(pcr_fit *f) {
+    if (f->group_partials_d) hipFree(f->group_partials_d);
+    if (f->tickets_d) hipFree(f->tickets_d);
+    f->group_partials_d = nullptr;
+    f->tickets_d = nullptr;
+    const size_t ng = (f->nb + 63u) / 64u;
+    hipError_t e = hipMalloc(&f->group_partials_d, sizeof(double) * 17 * (ng ? ng : 1));
+    if (e == hipSuccess) e = hipMalloc(&f->tickets_d, sizeof(uint32_t) * (1 + ng));
+    if (e == hipSuccess) e = hipMemsetAsync(f->tickets_d, 0, sizeof(uint32_t) * (1 + ng), f->ctx->stream);
+    f->args.group_partials = f->group_partials_d;
+    f->args.tickets = f->tickets_d;
+    return e;
+}
+
+// the two device copies of the arguments: [0] the step folds, [1] the step folds and solves
+static void fit_upload_args(pcr_fit *f) {
+    StepArgs A = f->args;
+    A.fit_inline = nullptr;
+    A.fit_traj = nullptr;
+    hipLaunchKernelGGL(set_args_kernel, dim3(1), dim3(256), 0, f->ctx->stream, A, f->args_d);
+    A.fit_inline = f->dev_d;
+    A.fit_traj = f->traj_d;
+    hipLaunchKernelGGL(set_args_kernel, dim3(1), dim3(256), 0, f->ctx->stream, A, f->args_d + 1);
+}
+
 // args_d: a device copy of A (set_args_kernel), what the filtered kernel reads its arguments from
-static void launch_step_kernels(pcr_ctx *ctx, const pcr_index *src, const StepArgs &A, uint32_t nb, uint32_t k,
+// Returns true when the launch also folded (and, if args_d says so, solved) in the step kernel itself.
+static bool launch_step_kernels(pcr_ctx *ctx, const pcr_index *src, const StepArgs &A, uint32_t nb, uint32_t k,
                                 double *partials_d, const StepArgs *args_d) {
     // CPointCloud::transform of the whole source (:73-74): the grid kernels do it candidate by candidate as they
     // search; a materialised copy (in index order) is only made for the brute-force kernel, or on request (tune 4)
@@ -697,10 +803,11 @@ static void launch_step_kernels(pcr_ctx *ctx, const pcr_index *src, const StepAr
             else
                 hipLaunchKernelGGL(icp_step_fast_kernel<4>, dim3(nb), dim3(256), 0, ctx->stream, args_d);
         }
+        if (A.tickets) return true;  // folded (and, with fit_inline in *args_d, solved) by the step kernel's last block
         ProfScope ps(ctx, PCR_PROF_FOLD);
         hipLaunchKernelGGL(fold_partials_kernel, dim3(17), dim3(256), 0, ctx->stream, (const double *)A.block_partials, nb,
                            partials_d);
-        return;
+        return false;
     }
     const bool on_the_fly = src->kind == PCR_INDEX_GRID &&
                             (g_tune[4] == 2 || (g_tune[4] == 0 && 24.0 * (double)A.m < 11.2 * (double)src->n + 6.0e6));
@@ -737,11 +844,12 @@ static void launch_step_kernels(pcr_ctx *ctx, const pcr_index *src, const StepAr
             LAUNCH_STEP(32);
     }
 #undef LAUNCH_STEP
-    {
+    if (!A.tickets) {
         ProfScope ps(ctx, PCR_PROF_FOLD);
         hipLaunchKernelGGL(fold_partials_kernel, dim3(17), dim3(256), 0, ctx->stream, (const double *)A.block_partials, nb,
                            partials_d);
     }
+    return false;
 }
 
 // argument checks and the iteration-independent part of StepArgs, shared by the single step and the fit loop
@@ -794,6 +902,9 @@ struct StepScratch {
     StepDyn dyn;
     StepArgs args;
 };
+// the in-kernel fold's scratch for nb blocks follows a StepScratch: the tickets (padded to 8 bytes), then the group partials
+static size_t fold_tickets_bytes(uint32_t nb) { return (sizeof(uint32_t) * (1 + (nb + 63u) / 64u) + 7) & ~(size_t)7; }
+static size_t fold_scratch_bytes(uint32_t nb) { return fold_tickets_bytes(nb) + sizeof(double) * 17 * ((nb + 63u) / 64u); }
 
 // What pcr_icp_step_d and pcr_icp_step_noalloc_d share: argument checks, the per-iteration constants, the launches.
 // dyn_d and block_partials_d are the step's scratch (device memory beyond inputs and outputs); who owns them is the
@@ -801,8 +912,8 @@ struct StepScratch {
 static int step_enqueue(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const uint32_t *sample_idx_d,
                         uint32_t sample_begin, uint32_t m, const double R[9], const double T[3], uint32_t k,
                         double thr_fwd_sq, double thr_rev_sq, uint32_t flags, double *partials_d, uint32_t *out_fwd_d,
-                        uint32_t *out_rev_d, uint8_t *out_keep_d, StepScratch *sc_d, double *block_partials_d,
-                        const char *who) {
+                        uint32_t *out_rev_d, uint8_t *out_keep_d, StepScratch *sc_d, double *group_partials_d,
+                        uint32_t *tickets_d, double *block_partials_d, const char *who) {
     StepArgs A;
     int rc = prepare_step_args(ctx, src, tgt, sample_idx_d, sample_begin, m, k, thr_fwd_sq, thr_rev_sq, flags, A, who);
     if (rc != PCR_OK) return rc;
@@ -824,6 +935,9 @@ static int step_enqueue(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt
     }
     A.block_partials = block_partials_d;
     A.dyn = &sc_d->dyn;
+    A.group_partials = group_partials_d;
+    A.tickets = tickets_d;  // zero here, and every launch leaves them so
+    A.partials_out = partials_d;
     // the per-iteration values and the arguments travel as kernel arguments of tiny kernels: stream-ordered, no staging
     hipLaunchKernelGGL(set_dyn_kernel, dim3(1), dim3(1), 0, ctx->stream, D, &sc_d->dyn);
     hipLaunchKernelGGL(set_args_kernel, dim3(1), dim3(256), 0, ctx->stream, A, &sc_d->args);
@@ -849,10 +963,14 @@ int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
         PCR_HIP(hipMalloc(&ctx->block_partials_d, sizeof(double) * 17 * (size_t)nb));
         ctx->block_partials_cap = (size_t)nb * 17;
     }
-    StepScratch *dyn_d = (StepScratch *)ctx_scratch(ctx, 5, sizeof(StepScratch));
+    StepScratch *dyn_d = (StepScratch *)ctx_scratch(ctx, 5, sizeof(StepScratch) + fold_scratch_bytes(nb));
     if (!dyn_d) return PCR_E_NOMEM;
+    // the scratch is laid out per call (the number of groups varies with m): the tickets are cleared per call
+    uint32_t *tickets_d = (uint32_t *)(dyn_d + 1);
+    double *gp_d = (double *)((char *)tickets_d + fold_tickets_bytes(nb));
+    PCR_HIP(hipMemsetAsync(tickets_d, 0, fold_tickets_bytes(nb), ctx->stream));
     return step_enqueue(ctx, src, tgt, sample_idx_d, sample_begin, m, R, T, k, thr_fwd_sq, thr_rev_sq, flags, partials_d,
-                        out_fwd_d, out_rev_d, out_keep_d, dyn_d, ctx->block_partials_d, "pcr_icp_step_d");
+                        out_fwd_d, out_rev_d, out_keep_d, dyn_d, gp_d, tickets_d, ctx->block_partials_d, "pcr_icp_step_d");
 }
 
 // ---- the entry point that allocates nothing (include/pcr.h: pcr_icp_step_noalloc_d) ------------------------------
@@ -863,6 +981,8 @@ int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
 // the process ends.
 struct NoAllocScratch {
     StepScratch step;
+    double group_partials[17 * (size_t)(PCR_NOALLOC_MAX_SAMPLES / 256u / 64u)];
+    uint32_t tickets[2 + PCR_NOALLOC_MAX_SAMPLES / 256u / 64u];  // zero-initialised; every launch leaves them zero
     double block_partials[17 * (size_t)(PCR_NOALLOC_MAX_SAMPLES / 256u)];
 };
 static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocScratch)];
@@ -895,7 +1015,8 @@ int pcr_icp_step_noalloc_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *
     PCR_REQUIRE(S, "pcr_icp_step_noalloc_d: no scratch on device %d (set up by pcr_ctx_create)", ctx->device);
     PCR_HIP(hipSetDevice(ctx->device));
     return step_enqueue(ctx, src, tgt, sample_idx_d, sample_begin, m, R, T, k, thr_fwd_sq, thr_rev_sq, flags, partials_d,
-                        out_fwd_d, out_rev_d, out_keep_d, &S->step, S->block_partials, "pcr_icp_step_noalloc_d");
+                        out_fwd_d, out_rev_d, out_keep_d, &S->step, S->group_partials, S->tickets, S->block_partials,
+                        "pcr_icp_step_noalloc_d");
 }
 
 int pcr_icp_step(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const uint32_t *sample_idx, uint32_t m,
@@ -993,6 +1114,8 @@ int pcr_fit_destroy(pcr_fit *f) {
     if (f->traj_d) hipFree(f->traj_d);
     if (f->samples_d) hipFree(f->samples_d);
     if (f->args_d) hipFree(f->args_d);
+    if (f->group_partials_d) hipFree(f->group_partials_d);
+    if (f->tickets_d) hipFree(f->tickets_d);
     if (f->dk_d) hipFree(f->dk_d);
     delete f;
     return PCR_OK;
@@ -1038,7 +1161,8 @@ int pcr_fit_create(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
     if (e == hipSuccess) e = hipMalloc(&f->partials_d, sizeof(double) * 32);
     if (e == hipSuccess) e = hipMalloc(&f->block_partials_d, sizeof(double) * 17 * (size_t)(f->nb ? f->nb : 1));
     if (e == hipSuccess && traj_cap) e = hipMalloc(&f->traj_d, sizeof(double) * 14 * (size_t)traj_cap);
-    if (e == hipSuccess) e = hipMalloc(&f->args_d, sizeof(StepArgs));
+    if (e == hipSuccess) e = hipMalloc(&f->args_d, sizeof(StepArgs) * 2);
+    if (e == hipSuccess) e = fit_alloc_fold(f);
     if (e == hipSuccess && m) e = hipMalloc(&f->dk_d, sizeof(float) * (size_t)m);
     if (e != hipSuccess) {
         set_last_error("pcr_fit_create: allocation failed: %s", hipGetErrorString(e));
@@ -1048,7 +1172,8 @@ int pcr_fit_create(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
     f->args.dyn = &f->dev_d->dyn;
     f->args.block_partials = f->block_partials_d;
     f->args.dk_io = f->dk_d;
-    hipLaunchKernelGGL(set_args_kernel, dim3(1), dim3(256), 0, ctx->stream, f->args, f->args_d);
+    f->args.partials_out = f->partials_d;
+    fit_upload_args(f);
     const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, zero[3] = {0, 0, 0};
     rc = pcr_fit_reset(f, eye, zero);
     if (rc != PCR_OK) {
@@ -1087,7 +1212,8 @@ int pcr_fit_set_samples(pcr_fit *f, const uint32_t *sample_idx, uint32_t m) {
     f->args.sample_begin = 0;
     f->args.m = m;
     f->nb = nb;
-    hipLaunchKernelGGL(set_args_kernel, dim3(1), dim3(256), 0, f->ctx->stream, f->args, f->args_d);
+    PCR_HIP(fit_alloc_fold(f));
+    fit_upload_args(f);
     PCR_HIP(hipGetLastError());
     return PCR_OK;
 }
@@ -1124,6 +1250,21 @@ int pcr_fit_enqueue_step(pcr_fit *f) {
         return PCR_OK;
     }
     launch_step_kernels(f->ctx, f->src, f->args, f->nb, f->kc, f->partials_d, f->args_d);
+    PCR_HIP(hipGetLastError());
+    return PCR_OK;
+}
+
+int pcr_fit_enqueue_iteration(pcr_fit *f) {
+    PCR_REQUIRE(f, "pcr_fit_enqueue_iteration: NULL argument");
+    PCR_HIP(hipSetDevice(f->ctx->device));
+    bool solved = false;
+    if (f->nb == 0)
+        PCR_HIP(hipMemsetAsync(f->partials_d, 0, sizeof(double) * 17, f->ctx->stream));
+    else
+        solved = launch_step_kernels(f->ctx, f->src, f->args, f->nb, f->kc, f->partials_d, f->args_d + 1);
+    if (!solved)
+        hipLaunchKernelGGL(fit_solve_kernel, dim3(1), dim3(64), 0, f->ctx->stream, f->dev_d, (const double *)f->partials_d,
+                           f->traj_d);
     PCR_HIP(hipGetLastError());
     return PCR_OK;
 }

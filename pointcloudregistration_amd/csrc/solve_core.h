@@ -35,89 +35,125 @@ PCR_HD inline void cross(const double *a, const double *b, double *o) {
 
 PCR_HD inline double norm3(const double *a) { return sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
 
+// One Jacobi rotation of columns I < J of A (and of V), every index a compile-time constant so that A and V live in
+// registers on the device (a run-time column index sends them to scratch memory, and the one thread that solves
+// then waits on memory for most of its life).  false: the columns already are orthogonal to within two units of
+// roundoff -- a stricter test is not reachable in general (gamma then hovers at rounding noise and the sweeps run
+// to the limit).
+template <int I, int J>
+PCR_HD inline bool jacobi_pair(double *A, double *V) {
+    double alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        alpha += A[I * 3 + r] * A[I * 3 + r];
+        beta += A[J * 3 + r] * A[J * 3 + r];
+        gamma += A[I * 3 + r] * A[J * 3 + r];
+    }
+    if (fabs(gamma) <= 4.440892098500626e-16 * sqrt(alpha * beta)) return false;
+    const double zeta = (beta - alpha) / (2.0 * gamma);
+    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double ai = A[I * 3 + r], aj = A[J * 3 + r];
+        A[I * 3 + r] = c * ai - s * aj;
+        A[J * 3 + r] = s * ai + c * aj;
+        const double vi = V[I * 3 + r], vj = V[J * 3 + r];
+        V[I * 3 + r] = c * vi - s * vj;
+        V[J * 3 + r] = s * vi + c * vj;
+    }
+    return true;
+}
+
+// columns I < J of A and V, and their singular values, into descending order (a stable exchange: only on strict >)
+template <int I, int J>
+PCR_HD inline void order_pair(double *sig, double *A, double *V) {
+    if (sig[J] > sig[I]) {
+        double t = sig[I];
+        sig[I] = sig[J];
+        sig[J] = t;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            t = A[I * 3 + r];
+            A[I * 3 + r] = A[J * 3 + r];
+            A[J * 3 + r] = t;
+            t = V[I * 3 + r];
+            V[I * 3 + r] = V[J * 3 + r];
+            V[J * 3 + r] = t;
+        }
+    }
+}
+
 // H = U diag(S) V^T, S descending, U and V orthogonal.
 PCR_HD inline void svd3_hestenes(const double *H, double *U, double *S, double *V) {
     double A[9];
     double scale = 0;
+#pragma unroll
     for (int i = 0; i < 9; ++i) scale = fmax(scale, fabs(H[i]));
     const double inv = scale > 0 ? 1.0 / scale : 1.0;
+#pragma unroll
     for (int i = 0; i < 9; ++i) A[i] = H[i] * inv;
-    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    for (int i = 0; i < 9; ++i) V[i] = I3[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) V[i] = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 60; ++sweep) {
-        bool rotated = false;
-        for (int i = 0; i < 2; ++i)
-            for (int j = i + 1; j < 3; ++j) {
-                double alpha = 0, beta = 0, gamma = 0;
-                for (int r = 0; r < 3; ++r) {
-                    alpha += el(A, r, i) * el(A, r, i);
-                    beta += el(A, r, j) * el(A, r, j);
-                    gamma += el(A, r, i) * el(A, r, j);
-                }
-                // orthogonal to within two units of roundoff: a stricter test is not reachable in general (gamma
-                // then hovers at rounding noise and the sweeps run to the limit -- 50+ us on one device thread)
-                if (fabs(gamma) <= 4.440892098500626e-16 * sqrt(alpha * beta)) continue;
-                rotated = true;
-                const double zeta = (beta - alpha) / (2.0 * gamma);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-                for (int r = 0; r < 3; ++r) {
-                    const double ai = el(A, r, i), aj = el(A, r, j);
-                    el(A, r, i) = c * ai - s * aj;
-                    el(A, r, j) = s * ai + c * aj;
-                    const double vi = el(V, r, i), vj = el(V, r, j);
-                    el(V, r, i) = c * vi - s * vj;
-                    el(V, r, j) = s * vi + c * vj;
-                }
-            }
+        bool rotated = jacobi_pair<0, 1>(A, V);
+        rotated |= jacobi_pair<0, 2>(A, V);
+        rotated |= jacobi_pair<1, 2>(A, V);
         if (!rotated) break;
     }
-    // columns of A are now orthogonal: sigma_i = |col_i|
-    int order[3] = {0, 1, 2};
+    // columns of A are now orthogonal: sigma_i = |col_i|; descending (the selection order of the exchanges below is
+    // the one a selection sort over an index array makes: (0,1), (0,2), (1,2))
     double sig[3];
+#pragma unroll
     for (int i = 0; i < 3; ++i) sig[i] = norm3(&A[i * 3]);
-    for (int i = 0; i < 3; ++i)
-        for (int j = i + 1; j < 3; ++j)
-            if (sig[order[j]] > sig[order[i]]) {
-                int t = order[i];
-                order[i] = order[j];
-                order[j] = t;
-            }
-    double Vs[9];
+    order_pair<0, 1>(sig, A, V);
+    order_pair<0, 2>(sig, A, V);
+    order_pair<1, 2>(sig, A, V);
     int rank = 0;
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const int o = order[i];
-        S[i] = sig[o] * scale;
-        for (int r = 0; r < 3; ++r) el(Vs, r, i) = el(V, r, o);
-        if (sig[o] > 1e-300 && sig[o] > 1e-15 * sig[order[0]]) {
-            for (int r = 0; r < 3; ++r) el(U, r, i) = el(A, r, o) / sig[o];
+        S[i] = sig[i] * scale;
+        if (sig[i] > 1e-300 && sig[i] > 1e-15 * sig[0]) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) U[i * 3 + r] = A[i * 3 + r] / sig[i];
             rank = i + 1;
         }
     }
-    for (int i = 0; i < 9; ++i) V[i] = Vs[i];
     // complete U to an orthonormal basis when H is rank deficient (planar / collinear pair sets)
     if (rank == 0) {
-        for (int i = 0; i < 9; ++i) U[i] = I3[i];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) U[i] = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
     } else if (rank == 1) {
         double e[3] = {0, 0, 0};
-        int m = 0;  // axis least aligned with u0
-        for (int r = 1; r < 3; ++r)
-            if (fabs(el(U, r, 0)) < fabs(el(U, m, 0))) m = r;
-        e[m] = 1.0;
+        // axis least aligned with u0
+        const double a0 = fabs(U[0]), a1 = fabs(U[1]), a2 = fabs(U[2]);
+        int m = 0;
+        double am = a0;
+        if (a1 < am) {
+            m = 1;
+            am = a1;
+        }
+        if (a2 < am) m = 2;
+        e[0] = m == 0 ? 1.0 : 0.0;
+        e[1] = m == 1 ? 1.0 : 0.0;
+        e[2] = m == 2 ? 1.0 : 0.0;
         double u1[3], u2[3];
         cross(&U[0], e, u1);
         const double n1 = norm3(u1);
+#pragma unroll
         for (int r = 0; r < 3; ++r) u1[r] /= n1;
         cross(&U[0], u1, u2);
+#pragma unroll
         for (int r = 0; r < 3; ++r) {
-            el(U, r, 1) = u1[r];
-            el(U, r, 2) = u2[r];
+            U[3 + r] = u1[r];
+            U[6 + r] = u2[r];
         }
     } else if (rank == 2) {
         double u2[3];
         cross(&U[0], &U[3], u2);
         const double n2 = norm3(u2);
-        for (int r = 0; r < 3; ++r) el(U, r, 2) = u2[r] / n2;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) U[6 + r] = u2[r] / n2;
     }
 }
 

@@ -225,10 +225,7 @@ bool CIterativeFit::__fitLoopFused(Eigen::Matrix3d &vioR, ColVector3 &vioT) {
     while (Status == PCR_OK) {
         // a batch of iterations without the host in between; once the criteria fire the rest of a batch is no-ops
         const unsigned int Batch = std::min(16u, Budget - Enqueued);
-        for (unsigned int i = 0; i < Batch && Status == PCR_OK; ++i) {
-            Status = pcr_fit_enqueue_step(pFit);
-            if (Status == PCR_OK) Status = pcr_fit_enqueue_solve(pFit);
-        }
+        for (unsigned int i = 0; i < Batch && Status == PCR_OK; ++i) Status = pcr_fit_enqueue_iteration(pFit);
         Enqueued += Batch;
         if (Status == PCR_OK) Status = pcr_fit_read(pFit, ReadR, ReadT, &Iterations, &State, NULL, NULL, NULL, 0);
         if (Iterations < Enqueued || Enqueued >= Budget) break;  // stopped by itself, or out of budget
