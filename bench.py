@@ -89,6 +89,25 @@ def cpu_baseline(src, tgt, R0, T0, k, sdft, ndft, budget_s=25.0):
             "seconds_per_iteration": s_multi, "single_thread_seconds_per_iteration": s_single}
 
 
+def spawn_ranks(n):
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,6 +120,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-knn", action="store_true")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: be the launcher.  N fresh child processes, one per GPU, started
+    # BEFORE anything here touches the GPU; rank 0's single JSON line is passed through.  (Never a silent one-GPU run.)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     # Libraries underneath (RCCL prints a version banner) write to stdout; the contract is ONE JSON line there.
     # Everything but that line goes to stderr: fd 1 is pointed at fd 2 until the result is printed.
@@ -133,7 +157,7 @@ def main():
         else:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node = --gpus"
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node = --gpus"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -173,6 +197,35 @@ def main():
                    traj_cap=max(args.steps, args.warmup, 1))
     part_t = fit.partials_tensor()
 
+    # The exchange: the library's own in-stream RCCL all-reduce (pcr_allreduce_partials, on the stream the kernels run
+    # on: no side stream, no event hops) -- or, if that cannot be set up on every rank, torch.distributed's communicator.
+    # PCR_BENCH_COMM=torch forces the latter.
+    comm, exchange = None, "none"
+    if world > 1 or force_dist:
+        exchange = "torch.distributed all_reduce (gloo)" if rehearse else "torch.distributed all_reduce (RCCL)"
+        if not rehearse and os.environ.get("PCR_BENCH_COMM", "lib") == "lib":
+            uid = [None]
+            if rank == 0:
+                try:
+                    uid = [capi.Comm.unique_id()]
+                except Exception as e:  # RCCL not loadable: every rank learns it from the broadcast below
+                    print(f"bench: pcr_comm_unique_id failed ({e}); using torch.distributed", file=sys.stderr)
+            dist.broadcast_object_list(uid, src=0)
+            ok = 0
+            if uid[0] is not None:
+                try:
+                    comm = capi.Comm(ctx, rank, world, uid[0])
+                    ok = 1
+                except Exception as e:
+                    print(f"bench: rank {rank}: pcr_comm_create failed ({e})", file=sys.stderr)
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                exchange = "pcr_allreduce_partials (RCCL, in-stream)"
+            else:
+                comm = None
+    part_ptr = part_t.data_ptr()
+
     def enqueue(steps):
         for _ in range(steps):
             if not (world > 1 or force_dist):
@@ -182,7 +235,10 @@ def main():
             if world > 1 or force_dist:
                 if rehearse:
                     torch.cuda.synchronize()  # gloo stages through the host: tell a stalled kernel from a stalled exchange
-                dist.all_reduce(part_t)
+                if comm is not None:
+                    comm.allreduce_partials(part_ptr)
+                else:
+                    dist.all_reduce(part_t)
             fit.solve()
 
     def barrier():
@@ -257,7 +313,7 @@ def main():
                                    f"source point a sample, {args.steps} ICRP iterations from a coarse alignment "
                                    f"(known transform perturbed by ~1.5 point spacings)",
                        "points_per_cloud": n, "k": k, "parallelism": f"sample-sharded x{world}, clouds+indices "
-                       "replicated, 17-double all-reduce per iteration"},
+                       "replicated, 17-double all-reduce per iteration", "exchange": exchange},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
@@ -279,6 +335,8 @@ def main():
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if comm is not None:
+        comm.close()
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()

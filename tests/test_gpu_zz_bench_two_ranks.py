@@ -30,6 +30,10 @@ def test_two_rank_bench_adds_up_to_the_single_rank_fit():
     two = _bench({"PCR_BENCH_REHEARSE_ONE_GPU": "1"},
                  ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                   "--master-port", "29577"], ["--gpus", "2"])
+    # `python bench.py --gpus 2` with no launcher: bench.py starts its own ranks (and never quietly measures one GPU)
+    own = _bench({"PCR_BENCH_REHEARSE_ONE_GPU": "1"}, [], ["--gpus", "2"])
+    assert own["n_gpus"] == 2 and own["fit"]["kept_pairs_last"] == two["fit"]["kept_pairs_last"]
+    assert abs(own["fit"]["mse_last"] - two["fit"]["mse_last"]) <= 1e-12 * two["fit"]["mse_last"]
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["steps"] == 6
     assert two["fit"]["kept_pairs_last"] == one["fit"]["kept_pairs_last"] > 50000     # integer count: exact
     assert abs(two["fit"]["mse_last"] - one["fit"]["mse_last"]) <= 1e-9 * one["fit"]["mse_last"]
