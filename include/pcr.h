@@ -20,6 +20,9 @@
  *     from the query; on exact ties the reference keeps the first one visited in
  *     KD-tree order (Common/KNNSearch.h:75) and this library keeps the lowest index.
  *   - a context is used by one host thread at a time; distinct contexts are independent.
+ *     A built index is read-only: any context ON THE SAME DEVICE may search it, step on it or fit on it, and any
+ *     number of them at the same time (an index must outlive every fit created on it, and is freed by the context
+ *     that built it being idle).
  *     Entry points without a _d suffix are synchronous; _d entry points enqueue on the
  *     context's stream and return (call pcr_ctx_synchronize, or order later work on the
  *     same stream).
@@ -59,9 +62,7 @@ const char *pcr_version(void);
 /* Tuning knobs for experiments (no reference counterpart).  Results do not depend on them.
  *   key 2: log2 of the brick edge (in cells) used to order the samples of a step
  *   key 3: 1 = leave K-NN query batches in the caller's order
- *   key 4: how the ICP step gets at the transformed source for its reverse search: 0 = choose by cost (a
- *          materialised copy when about every source point is a sample, else candidate by candidate while searching),
- *          1 = always the copy, 2 = always on the fly
+ *   key 4: (unused: the transformed copy of the source it chose is gone -- the reverse search always moves candidates as it reads them)
  *   key 5: 1 = the ICP step never uses the fp32-filtered kernel (every candidate goes through the fp64 walk) */
 int pcr_tune(int key, int value);
 

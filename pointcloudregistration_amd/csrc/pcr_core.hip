@@ -872,7 +872,6 @@ int pcr_index_free(pcr_index *ix) {
     if (!ix) return PCR_OK;
     hipSetDevice(ix->ctx->device);
     if (ix->pts_d) hipFree(ix->pts_d);
-    if (ix->tpts_d) hipFree(ix->tpts_d);
     if (ix->shadow_d) hipFree(ix->shadow_d);
     for (int l = 0; l < PCR_MAX_LEVELS; ++l) {
         if (ix->cs_raw_d[l]) hipFree(ix->cs_raw_d[l]);
@@ -1084,6 +1083,7 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
     LevelBuild B;
     memset(&B, 0, sizeof B);
     uint32_t *cursor_d = nullptr, *stats16_d = nullptr;
+    Pt4 *sort_tmp_d = nullptr;
     unsigned long long *stats_d = nullptr;
     uint8_t *lvl_d = nullptr;
 #define BUILD_HIP(call)                                                                             \
@@ -1102,7 +1102,6 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
     } while (0)
 
     BUILD_HIP(hipMalloc(&ix->pts_d, sizeof(Pt4) * (size_t)n));
-    BUILD_HIP(hipMalloc(&ix->tpts_d, sizeof(Pt4) * (size_t)n));
     BUILD_HIP(hipMalloc(&ix->pos_of_d, sizeof(uint32_t) * (size_t)n));
     BUILD_HIP(hipMalloc(&ix->order_d, sizeof(uint32_t) * (size_t)n));
 
@@ -1148,7 +1147,7 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
             ix->info.mean_occupancy = n;
             ix->info.max_occupancy = n;
             ix->info.levels = 1;
-            ix->info.device_bytes = (sizeof(Pt4) * 2 + 4) * (uint64_t)n;
+            ix->info.device_bytes = (sizeof(Pt4) + 8) * (uint64_t)n;
             *out = ix;
             return PCR_OK;
         }
@@ -1210,11 +1209,16 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
                                    (const uint8_t *)lvl_d, (uint8_t)l, cursor_d, seg);
                 hipLaunchKernelGGL(cell_order_kernel, dim3((unsigned)((B.cells + 255) / 256)), dim3(256), 0, ctx->stream,
                                    (const uint32_t *)B.counts_d, B.cells, seg);
-                if (B.stats_h[1] > PCR_HEAVY_CELL) BUILD_RC(sort_heavy_cells(ctx, B.counts_d, B.cells, n_l, seg, ix->tpts_d + off));
+                if (B.stats_h[1] > PCR_HEAVY_CELL) {  // (scratch of the segmented sort: as large as the level)
+                    BUILD_HIP(hipMalloc(&sort_tmp_d, sizeof(Pt4) * (size_t)n_l));
+                    BUILD_RC(sort_heavy_cells(ctx, B.counts_d, B.cells, n_l, seg, sort_tmp_d));
+                }
                 BUILD_HIP(hipStreamSynchronize(ctx->stream));
                 BUILD_HIP(hipGetLastError());
                 hipFree(cursor_d);
                 cursor_d = nullptr;
+                if (sort_tmp_d) hipFree(sort_tmp_d);
+                sort_tmp_d = nullptr;
             }
             // ---- strip table of the level (lets the shell search skip 8x8 blocks of empty rows) ----
             const int gy8 = (B.G.g[1] + 7) / 8, gz8 = (B.G.g[2] + 7) / 8;
@@ -1307,7 +1311,7 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
         ix->info.mean_occupancy = (double)n / (double)(occupied_total ? occupied_total : 1);
         ix->info.max_occupancy = max_occ;
         ix->info.levels = (uint32_t)M.levels;
-        ix->info.device_bytes = (sizeof(Pt4) * 2 + 8 + (ix->shadow_d ? 16 : 0)) * (uint64_t)n + 4 * (cells_total + M.levels) + cells_total / 8;
+        ix->info.device_bytes = (sizeof(Pt4) + 8 + (ix->shadow_d ? 16 : 0)) * (uint64_t)n + 4 * (cells_total + M.levels) + cells_total / 8;
     }
     release(B);
     if (stats_d) hipFree(stats_d);
@@ -1319,6 +1323,7 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
 fail:
     release(B);
     if (cursor_d) hipFree(cursor_d);
+    if (sort_tmp_d) hipFree(sort_tmp_d);
     if (stats_d) hipFree(stats_d);
     if (stats16_d) hipFree(stats16_d);
     if (lvl_d) hipFree(lvl_d);

@@ -66,23 +66,9 @@ PCR_HD inline bool make_dyn(const double *R, const double *T, const double *c_sr
 __global__ void set_dyn_kernel(StepDyn value, StepDyn *dst) { *dst = value; }
 
 
-__global__ void __launch_bounds__(256) transform_kernel(const Pt4 *__restrict__ in, uint32_t n,
-                                                        const StepDyn *__restrict__ dyn, Pt4 *__restrict__ out) {
-    if (dyn->done) return;
-    const Rigid M = dyn->M;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const Pt4 s = in[i];
-        Pt4 o;
-        xform(M, s.x, s.y, s.z, o.x, o.y, o.z);
-        o.w = s.w;
-        out[i] = o;
-    }
-}
-
 struct FitDev;
 struct StepArgs {
     MultiView src, tgt;
-    const Pt4 *tsrc;             // transformed source, parallel to src.pts
     const uint32_t *src_pos_of;  // original index -> position in src.pts
     const uint32_t *src_order;   // positions of src.pts in brick order (processing order of "all samples")
     const uint32_t *sample_idx;  // NULL: samples are positions [sample_begin, sample_begin+m)
@@ -247,10 +233,11 @@ __device__ __forceinline__ void fold_in_kernel(AP A, uint32_t lb, uint32_t nb) {
 
 // MULTI: either index has more than one level (clouds of very uneven density); the single-level instance is the
 // plain search on level 0, with none of the level loop in its code.
-// XF: the reverse search moves its candidates by (R,T) as it reads them (from the source index itself) instead of
-// reading a transformed copy of the source: no transform_kernel launch, no 64 B/point of HBM traffic per iteration
-// and -- what matters on several GPUs -- no per-rank work proportional to the WHOLE source.
-template <int KC, bool MULTI, bool XF>
+// The reverse search moves its candidates by (R,T) as it reads them, from the source index itself (CPointCloud::transform's
+// expression, so every distance is the one the reference gets from its transformed copy, :73-74): no copy is ever
+// written, an index holds no per-iteration state -- fits may share it -- and no rank of a sharded fit does work
+// proportional to the WHOLE source.
+template <int KC, bool MULTI>
 __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(StepArgs A) {
     const StepDyn *__restrict__ dynp = A.dyn;
     if (dynp->done) return;  // uniform over the grid
@@ -316,26 +303,19 @@ __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(Step
     rt.idx[0] = orig;
     const bool rev_active = need_rev && isfinite(sx) && isfinite(sy) && isfinite(sz);
     if (rev_active) {
-        const Pt4 *rcand = XF ? A.src.all : A.tsrc;
         if constexpr (MULTI)
-            multi_lane_search<1, XF>(A.src, rcand, qx, qy, qz, sx, sy, sz, PCR_INF, D.rev_bound_scale, D.rev_extra_margin, rt,
-                                     my_rows, &D.M);
+            multi_lane_search<1, true>(A.src, A.src.all, qx, qy, qz, sx, sy, sz, PCR_INF, D.rev_bound_scale, D.rev_extra_margin,
+                                       rt, my_rows, &D.M);
         else
-            lane_search<1, XF>(A.src.v[0], rcand, qx, qy, qz, sx, sy, sz, PCR_INF, D.rev_bound_scale, D.rev_extra_margin, rt,
-                               my_rows, &D.M);
+            lane_search<1, true>(A.src.v[0], A.src.all, qx, qy, qz, sx, sy, sz, PCR_INF, D.rev_bound_scale, D.rev_extra_margin,
+                                 rt, my_rows, &D.M);
     }
     uint32_t r = PCR_NO_INDEX;
     bool keep = false;
     if (need_rev) {
         r = rt.idx[0];
-        double dR;  // (CurSrcPoint - TmpPoint).squaredNorm()
-        if constexpr (XF) {
-            const Pt4 sp = A.src.all[r == orig ? pos : A.src_pos_of[r]];
-            dR = cand_d2<true>(&D.M, px, py, pz, sp);
-        } else {
-            const Pt4 pp = A.tsrc[r == orig ? pos : A.src_pos_of[r]];
-            dR = sqdist3(px, py, pz, pp.x, pp.y, pp.z);
-        }
+        const Pt4 sp = A.src.all[r == orig ? pos : A.src_pos_of[r]];
+        const double dR = cand_d2<true>(&D.M, px, py, pz, sp);  // (CurSrcPoint - TmpPoint).squaredNorm()
         keep = passF && dR < A.thr_rev;  // strict < (:98)
     }
     if (live) {
@@ -537,7 +517,13 @@ __global__ void __launch_bounds__(256) icp_step_brute_kernel(StepArgs A) {
     rt.idx[0] = found ? orig : PCR_NO_INDEX;
     for (uint32_t base = 0; base < A.src.n; base += 512) {
         const int cnt = (int)min(512u, A.src.n - base);
-        for (int u = threadIdx.x; u < cnt; u += 256) tile[u] = A.tsrc[base + u];
+        for (int u = threadIdx.x; u < cnt; u += 256) {  // the transformed source (:73-74), tile by tile as it is staged
+            const Pt4 sp = A.src.all[base + u];
+            Pt4 tp;
+            xform(D.M, sp.x, sp.y, sp.z, tp.x, tp.y, tp.z);
+            tp.w = sp.w;
+            tile[u] = tp;
+        }
         __syncthreads();
         if (found) tile_scan<1>(tile, cnt, qx, qy, qz, rt);
         __syncthreads();
@@ -546,8 +532,7 @@ __global__ void __launch_bounds__(256) icp_step_brute_kernel(StepArgs A) {
     uint32_t r = PCR_NO_INDEX;
     if (found) {
         r = rt.idx[0];
-        const Pt4 pp = A.tsrc[A.src_pos_of[r]];
-        const double dR = sqdist3(px, py, pz, pp.x, pp.y, pp.z);
+        const double dR = cand_d2<true>(&D.M, px, py, pz, A.src.all[A.src_pos_of[r]]);
         keep = passF && dR < A.thr_rev;
     }
     if (live) {
@@ -786,49 +771,14 @@ static void fit_upload_args(pcr_fit *f) {
 // Returns true when the launch also folded (and, if args_d says so, solved) in the step kernel itself.
 static bool launch_step_kernels(pcr_ctx *ctx, const pcr_index *src, const StepArgs &A, uint32_t nb, uint32_t k,
                                 double *partials_d, const StepArgs *args_d) {
-    // CPointCloud::transform of the whole source (:73-74): the grid kernels do it candidate by candidate as they
-    // search; a materialised copy (in index order) is only made for the brute-force kernel, or on request (tune 4)
-    // Which is cheaper depends on how many samples this launch serves: the copy costs ~11 us per million SOURCE points
-    // plus a launch, moving candidates on the fly ~24 us per million SAMPLES (measured, 1 M x 1 M, K=4).  A rank of a
-    // sharded fit, or a sampled fit, searches on the fly; a single GPU running every point as a sample copies.
-    // tune 4: 0 = by this rule, 1 = always copy, 2 = always on the fly.
-    // single-level grids with fp32 shadows and K <= 4: the filtered kernel (tune 5: 1 = never, for A/B runs and tests)
-    const bool fast = src->kind == PCR_INDEX_GRID && g_tune[5] != 1 && k <= 4 && A.src.levels == 1 && A.tgt.levels == 1 &&
-                      A.src.v[0].shadow && A.tgt.v[0].shadow && args_d;
-    if (fast) {
-        {
-            ProfScope ps(ctx, PCR_PROF_STEP);
-            if (k == 1)
-                hipLaunchKernelGGL(icp_step_fast_kernel<1>, dim3(nb), dim3(256), 0, ctx->stream, args_d);
-            else
-                hipLaunchKernelGGL(icp_step_fast_kernel<4>, dim3(nb), dim3(256), 0, ctx->stream, args_d);
-        }
-        if (A.tickets) return true;  // folded (and, with fit_inline in *args_d, solved) by the step kernel's last block
-        ProfScope ps(ctx, PCR_PROF_FOLD);
-        hipLaunchKernelGGL(fold_partials_kernel, dim3(17), dim3(256), 0, ctx->stream, (const double *)A.block_partials, nb,
-                           partials_d);
-        return false;
-    }
-    const bool on_the_fly = src->kind == PCR_INDEX_GRID &&
-                            (g_tune[4] == 2 || (g_tune[4] == 0 && 24.0 * (double)A.m < 11.2 * (double)src->n + 6.0e6));
-    if (!on_the_fly) {
-        ProfScope ps(ctx, PCR_PROF_TRANSFORM);
-        hipLaunchKernelGGL(transform_kernel, dim3(min(2048u, (src->n + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const Pt4 *)src->pts_d, src->n, A.dyn, src->tpts_d);
-    }
-#define LAUNCH_STEP(KC)                                                                                \
-    do {                                                                                               \
-        const bool multi__ = A.src.levels > 1 || A.tgt.levels > 1;                                     \
-        if (src->kind == PCR_INDEX_GRID && multi__ && on_the_fly)                                      \
-            hipLaunchKernelGGL((icp_step_grid_kernel<KC, true, true>), dim3(nb), dim3(256), 0, ctx->stream, A);  \
-        else if (src->kind == PCR_INDEX_GRID && multi__)                                               \
-            hipLaunchKernelGGL((icp_step_grid_kernel<KC, true, false>), dim3(nb), dim3(256), 0, ctx->stream, A); \
-        else if (src->kind == PCR_INDEX_GRID && on_the_fly)                                            \
-            hipLaunchKernelGGL((icp_step_grid_kernel<KC, false, true>), dim3(nb), dim3(256), 0, ctx->stream, A); \
-        else if (src->kind == PCR_INDEX_GRID)                                                          \
-            hipLaunchKernelGGL((icp_step_grid_kernel<KC, false, false>), dim3(nb), dim3(256), 0, ctx->stream, A); \
-        else                                                                                           \
-            hipLaunchKernelGGL(icp_step_brute_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, A);     \
+#define LAUNCH_STEP(KC)                                                                               \
+    do {                                                                                              \
+        if (src->kind == PCR_INDEX_GRID && (A.src.levels > 1 || A.tgt.levels > 1))                    \
+            hipLaunchKernelGGL((icp_step_grid_kernel<KC, true>), dim3(nb), dim3(256), 0, ctx->stream, A);  \
+        else if (src->kind == PCR_INDEX_GRID)                                                         \
+            hipLaunchKernelGGL((icp_step_grid_kernel<KC, false>), dim3(nb), dim3(256), 0, ctx->stream, A); \
+        else                                                                                          \
+            hipLaunchKernelGGL(icp_step_brute_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, A);    \
     } while (0)
     {
         ProfScope ps(ctx, PCR_PROF_STEP);
@@ -856,7 +806,7 @@ static bool launch_step_kernels(pcr_ctx *ctx, const pcr_index *src, const StepAr
 static int prepare_step_args(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const uint32_t *sample_idx_d,
                              uint32_t sample_begin, uint32_t m, uint32_t k, double thr_fwd_sq, double thr_rev_sq,
                              uint32_t flags, StepArgs &A, const char *who) {
-    PCR_REQUIRE(src->ctx == ctx && tgt->ctx == ctx, "%s: index belongs to another context", who);
+    PCR_REQUIRE(src->ctx->device == ctx->device && tgt->ctx->device == ctx->device, "%s: index lives on another device", who);
     PCR_REQUIRE(src->kind == tgt->kind, "%s: source and target index must be of the same kind", who);
     PCR_REQUIRE(k >= 1 && k <= tgt->n, "%s: k=%u out of range for %u target points", who, k, tgt->n);
     if (k > PCR_MAX_K) {
@@ -869,7 +819,6 @@ static int prepare_step_args(pcr_ctx *ctx, const pcr_index *src, const pcr_index
     memset(&A, 0, sizeof A);
     A.src = src->view;
     A.tgt = tgt->view;
-    A.tsrc = src->tpts_d;
     A.src_pos_of = src->pos_of_d;
     A.src_order = src->order_d;
     A.sample_idx = sample_idx_d;

@@ -85,7 +85,7 @@ struct MultiView {
 }  // namespace pcr
 
 // kernel classes timed by the optional profiling hooks (pcr_ctx_set_profiling)
-enum { PCR_PROF_TRANSFORM = 0, PCR_PROF_STEP = 1, PCR_PROF_FOLD = 2, PCR_PROF_KNN = 3, PCR_PROF_CLASSES = 4 };
+enum { PCR_PROF_TRANSFORM = 0 /* (no longer launched: kept so that the class numbers stay) */, PCR_PROF_STEP = 1, PCR_PROF_FOLD = 2, PCR_PROF_KNN = 3, PCR_PROF_CLASSES = 4 };
 constexpr int PCR_PROF_CAP = 1024;  // launches recorded per class between two reads
 
 struct pcr_prof {
@@ -169,7 +169,6 @@ struct pcr_index {
     int kind;  // PCR_INDEX_GRID or PCR_INDEX_BRUTE
     uint32_t n;
     pcr::Pt4 *pts_d;    // [n] cell order (GRID) / original order (BRUTE)
-    pcr::Pt4 *tpts_d;   // [n] same order, transformed by the current (R,T) -- scratch of the ICP step
     float4 *shadow_d;   // [n] same order: fp32 key-space copy (GridView::shadow), single-level grids only
     uint32_t *pos_of_d; // [n] original index -> position in pts_d
     uint32_t *order_d;  // [n] positions in pts_d ordered by grid brick: the processing order of "all samples"

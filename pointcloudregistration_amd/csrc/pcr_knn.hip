@@ -116,7 +116,7 @@ extern "C" {
 int pcr_knn_d(pcr_ctx *ctx, const pcr_index *ix, const double *q_d, uint32_t nq, uint32_t k, int order, double max_d2,
               uint32_t *out_idx_d, double *out_d2_d) {
     PCR_REQUIRE(ctx && ix && out_idx_d, "pcr_knn_d: NULL argument");
-    PCR_REQUIRE(ix->ctx == ctx, "pcr_knn_d: index belongs to another context");
+    PCR_REQUIRE(ix->ctx->device == ctx->device, "pcr_knn_d: index lives on another device");
     PCR_REQUIRE(k >= 1, "pcr_knn_d: k must be >= 1");
     PCR_REQUIRE(k <= ix->n, "pcr_knn_d: k=%u exceeds the %u indexed points (Common/KNNSearch.cpp:19)", k, ix->n);
     if (k > PCR_MAX_K) {

@@ -160,7 +160,7 @@ extern "C" int pcr_reject_centroid_dist(pcr_ctx *ctx, const pcr_index *src, cons
                                         const double *pair_q, uint32_t P, uint32_t msn, double msd, double cdf,
                                         uint8_t *out_keep, double *out_d, double *out_stat) {
     PCR_REQUIRE(ctx && src && tgt && out_keep, "pcr_reject_centroid_dist: NULL argument");
-    PCR_REQUIRE(src->ctx == ctx && tgt->ctx == ctx, "pcr_reject_centroid_dist: index belongs to another context");
+    PCR_REQUIRE(src->ctx->device == ctx->device && tgt->ctx->device == ctx->device, "pcr_reject_centroid_dist: index lives on another device");
     PCR_REQUIRE(src->kind == tgt->kind, "pcr_reject_centroid_dist: indices must be of the same kind");
     PCR_REQUIRE(P > 0 && pair_p && pair_q, "pcr_reject_centroid_dist: empty pair set (reference asserts, :27)");
     PCR_REQUIRE(msn >= 1 && msn <= src->n && msn <= tgt->n, "pcr_reject_centroid_dist: MSN=%u out of range", msn);

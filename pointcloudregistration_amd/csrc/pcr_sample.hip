@@ -133,7 +133,7 @@ int pcr_sample_random(pcr_ctx *ctx, uint32_t n, double ratio, uint64_t seed, uin
 
 int pcr_sample_grid(pcr_ctx *ctx, const pcr_index *index, uint32_t cap, uint32_t *out_idx, uint32_t *out_count) {
     PCR_REQUIRE(ctx && index && out_idx && out_count, "pcr_sample_grid: NULL argument");
-    PCR_REQUIRE(index->ctx == ctx, "pcr_sample_grid: index belongs to another context");
+    PCR_REQUIRE(index->ctx->device == ctx->device, "pcr_sample_grid: index lives on another device");
     PCR_REQUIRE(index->kind == PCR_INDEX_GRID, "pcr_sample_grid: needs a grid index");
     PCR_HIP(hipSetDevice(ctx->device));
     // every level of the index has cells of its own; the levels partition the cloud, so the picks are distinct

@@ -83,12 +83,10 @@ def test_device_loop_with_external_reduction(pcr, ctx):
     pa, pb = a.partials_tensor(), b.partials_tensor()
     import torch
     for _ in range(3):
-        a.step()
-        ctx.synchronize()      # the fixture's context has its own stream; torch works on another one
-        pa_mine = pa.clone()   # a and b share the source index's scratch: run them one after the other
+        a.step()               # (an index holds no per-iteration state: the two fits need no serialising)
         b.step()
-        ctx.synchronize()
-        tot = pa_mine + pb     # what an all-reduce leaves on every rank
+        ctx.synchronize()      # the fixture's context has its own stream; torch works on another one
+        tot = pa + pb          # what an all-reduce leaves on every rank
         pa.copy_(tot)
         pb.copy_(tot)
         torch.cuda.synchronize()
@@ -114,3 +112,32 @@ def test_rccl_allreduce_entry_point_single_rank(pcr, ctx):
     out = fit.run(g["R0"], g["T0"], 4, all_reduce=lambda _t: comm.allreduce_partials(ptr))
     assert (out["traj"] == plain["traj"]).all() and (out["R"] == plain["R"]).all()
     comm.close()
+
+
+def test_concurrent_fits_on_two_contexts_share_one_pair_of_indices(pcr, ctx):
+    """Indices are read-only: two contexts (two streams) fit on the SAME source and target index at the same time, from
+    different initial transforms, and each must reproduce what it gives when it runs alone."""
+    from pointcloudregistration_amd import synth
+    n = 120000
+    src, tgt, Rm, t = synth.registration_pair(n, n, 77)
+    six, tix = pcr.Index(ctx, pcr.Cloud(ctx, src), kind=pcr.INDEX_GRID), pcr.Index(ctx, pcr.Cloud(ctx, tgt), kind=pcr.INDEX_GRID)
+    U = tix.unique_sq_dist()
+    other = pcr.Context(ctx.device)
+    starts = [synth.coarse_initial_transform(Rm, t, n), synth.coarse_initial_transform(Rm, t, n, rot_spacings=0.7, trans_spacings=1.6)]
+    conv = pcr.ConvergenceParams.regcfg(12)
+    alone = [pcr.Fit(c, six, tix, 4, U * 36, U * 4, conv=conv, unique_sq_dist=U, traj_cap=16).run(R, T, 12)
+             for c, (R, T) in zip((ctx, other), starts)]
+    fits = [pcr.Fit(c, six, tix, 4, U * 36, U * 4, conv=conv, unique_sq_dist=U, traj_cap=16) for c in (ctx, other)]
+    for f, (R, T) in zip(fits, starts):
+        f.reset(R, T)
+    for _ in range(12):        # interleaved enqueues on two streams: the GPU overlaps them as it likes
+        for f in fits:
+            f.iterate()
+    both = [f.read() for f in fits]
+    for a, b in zip(alone, both):
+        assert a["iterations"] == b["iterations"] and a["state"] == b["state"]
+        assert (a["traj"] == b["traj"]).all() and (a["R"] == b["R"]).all() and (a["T"] == b["T"]).all()
+    assert alone[0]["pairs"] > 10000
+    for f in fits:
+        f.close()
+    other.close()

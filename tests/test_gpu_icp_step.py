@@ -80,31 +80,6 @@ def test_no_pair_survives(pcr, ctx):
     assert e.value.status == -5
 
 
-def test_transformed_copy_and_on_the_fly_reverse_search_agree_bit_for_bit(pcr, ctx):
-    """The reverse search reads a transformed copy of the source, or moves candidates by (R,T) as it reads them (what a
-    rank of a sharded fit does): the same arithmetic, so every index, flag and partial sum must be identical."""
-    from pointcloudregistration_amd import synth
-    src, tgt, Rm, t = synth.registration_pair(150000, 150000, 31)
-    six, tix = pcr.Index(ctx, pcr.Cloud(ctx, src), kind=pcr.INDEX_GRID), pcr.Index(ctx, pcr.Cloud(ctx, tgt), kind=pcr.INDEX_GRID)
-    U = tix.unique_sq_dist()
-    R, T = synth.coarse_initial_transform(Rm, t, 150000)
-    smp = np.random.default_rng(5).choice(150000, 20000, replace=False).astype(np.uint32)
-    out = {}
-    try:
-        for mode in (1, 2, 0):
-            pcr.lib().pcr_tune(4, mode)
-            out[mode] = [pcr.icp_step(ctx, six, tix, R, T, 4, U * 36.0, U * 4.0, exact=True),
-                         pcr.icp_step(ctx, six, tix, R, T, 4, U * 36.0, U * 4.0, exact=False),
-                         pcr.icp_step(ctx, six, tix, R, T, 1, U * 36.0, U * 4.0, sample_idx=smp, exact=True)]
-    finally:
-        pcr.lib().pcr_tune(4, 0)
-    for mode in (2, 0):
-        for a, b in zip(out[1], out[mode]):
-            for key in ("fwd", "rev", "keep", "partials"):
-                assert (a[key] == b[key]).all(), (mode, key)
-    assert out[1][0]["partials"][0] > 10000
-
-
 def test_filtered_kernel_equals_the_fp64_walk_bit_for_bit(pcr, ctx):
     """The fp32-filtered step kernel (fp32 keys select, fp64 decides and verifies; fast_search.h) against the kernel in
     which every candidate goes through the fp64 walk (pcr_tune key 5 = 1): every index, flag and partial sum."""
