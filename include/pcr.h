@@ -281,6 +281,19 @@ int pcr_fit_enqueue_solve(pcr_fit *fit);
 /* pcr_fit_enqueue_step + pcr_fit_enqueue_solve for a fit that needs no exchange in between (one GPU): where the step
  * runs as the filtered kernel, its last block folds the partials and runs the solve -- ONE launch per iteration. */
 int pcr_fit_enqueue_iteration(pcr_fit *fit);
+/* ---- many small fits, ONE launch per iteration ---------------------------------------------------
+ * The caller of the loop (CRegistartion::fineFit per scan pair, Registration.cpp:148-158; unit test/FineRegistration/
+ * TestFineRegistration.cpp:26-92) registers a scan set pair by pair: independent problems, each too small to fill
+ * the GPU (BASELINE config C4).  A batch ties existing fits of one context together: every pcr_fit_batch_enqueue_iteration
+ * advances ALL of them by one iteration in a single kernel launch (each fit folds and solves for itself in the last
+ * of its own blocks; a fit whose criteria have fired costs nothing in later launches).  The fits keep their own state:
+ * pcr_fit_reset before, pcr_fit_read after, exactly as for a fit run alone -- and with bit-identical results.
+ * Members must be on single-level grid indices with K <= 4 (K = 1 for all or for none); a member's sample set must not
+ * change while the batch exists.  The batch is destroyed before its members. */
+typedef struct pcr_fit_batch pcr_fit_batch;
+int pcr_fit_batch_create(pcr_ctx *ctx, pcr_fit *const *fits, uint32_t count, pcr_fit_batch **out);
+int pcr_fit_batch_enqueue_iteration(pcr_fit_batch *batch);
+int pcr_fit_batch_destroy(pcr_fit_batch *batch);
 /* synchronises the stream.  All outputs nullable; traj receives min(iterations, traj_cap, traj_rows) rows. */
 int pcr_fit_read(pcr_fit *fit, double R[9], double T[3], uint32_t *iterations, int *state, double *mse,
                  double *pairs, double *traj, uint32_t traj_rows);

@@ -85,6 +85,9 @@ SYMBOLS = {
     "pcr_fit_partials_d": (_vp, [_vp]),
     "pcr_fit_enqueue_solve": (C.c_int, [_vp]),
     "pcr_fit_enqueue_iteration": (C.c_int, [_vp]),
+    "pcr_fit_batch_create": (C.c_int, [_vp, C.POINTER(_vp), C.c_uint32, C.POINTER(_vp)]),
+    "pcr_fit_batch_enqueue_iteration": (C.c_int, [_vp]),
+    "pcr_fit_batch_destroy": (C.c_int, [_vp]),
     "pcr_fit_read": (C.c_int, [_vp, _dp, _dp, _up, C.POINTER(C.c_int), _dp, _dp, _dp, C.c_uint32]),
     "pcr_fit_destroy": (C.c_int, [_vp]),
     "pcr_comm_unique_id": (C.c_int, [C.c_char_p]),
@@ -173,7 +176,7 @@ class Context:
 
     def close(self):
         if self.h:
-            for cls in (Comm, Fit, Index, Cloud):  # dependants first, in dependency order
+            for cls in (Comm, FitBatch, Fit, Index, Cloud):  # dependants first, in dependency order
                 for child in [c for c in self._children if isinstance(c, cls)]:
                     child.close()
             lib().pcr_ctx_destroy(self.h)
@@ -413,6 +416,31 @@ class Fit:
     def close(self):
         if self.h:
             lib().pcr_fit_destroy(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FitBatch:
+    """pcr_fit_batch: fits of one context advanced together, one kernel launch per iteration."""
+
+    def __init__(self, ctx, fits):
+        self.ctx, self.fits = ctx, list(fits)
+        self.h = _vp()
+        ctx._children.add(self)
+        arr = (_vp * len(self.fits))(*[f.h for f in self.fits])
+        _check(lib().pcr_fit_batch_create(ctx.h, arr, len(self.fits), C.byref(self.h)), "pcr_fit_batch_create")
+
+    def iterate(self):
+        _check(lib().pcr_fit_batch_enqueue_iteration(self.h), "pcr_fit_batch_enqueue_iteration")
+
+    def close(self):
+        if self.h:
+            lib().pcr_fit_batch_destroy(self.h)
             self.h = _vp()
 
     def __del__(self):

@@ -11,6 +11,7 @@
 // kernel folds the block partials in a fixed order (bitwise reproducible run to run).
 #include <math.h>
 #include <string.h>
+#include <vector>
 #include "knn_device.h"
 #include "fast_search.h"
 #include "solve_core.h"
@@ -334,10 +335,10 @@ __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(Step
 // source: keys are taken in the SOURCE frame (q mapped back by R^-1; the key error bound is widened by R's deviation
 // from an isometry), and only the few candidates that reach the fp64 stage are moved by (R,T), with
 // CPointCloud::transform's expression.  Every index, flag and sum is bit-identical to icp_step_grid_kernel's (tested).
+// lb of nb: the block's place among the blocks of ITS problem (a launch may carry many: icp_step_batch_kernel)
 template <int KC>
-__global__ void __launch_bounds__(256, PCR_FAST_WAVES) icp_step_fast_kernel(const StepArgs *__restrict__ Ap) {
-    if (Ap->dyn->done) return;  // uniform over the grid
-    const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
+__device__ __forceinline__ void fast_step_body(const StepArgs *__restrict__ Ap, uint32_t lb, uint32_t nb) {
+    if (Ap->dyn->done) return;  // uniform over the problem's blocks
     const uint32_t t = lb * 256u + threadIdx.x;
     __shared__ uint2 rowtab[9][256];
     uint2 *my_rows = &rowtab[0][threadIdx.x];
@@ -459,8 +460,32 @@ __global__ void __launch_bounds__(256, PCR_FAST_WAVES) icp_step_fast_kernel(cons
         if (A->out_rev) A->out_rev[slot] = r;
         if (A->out_keep) A->out_keep[slot] = keep ? 1 : 0;
     }
-    block_reduce17(acc, A->block_partials, lb, gridDim.x);
-    fold_in_kernel(A, lb, gridDim.x);
+    block_reduce17(acc, A->block_partials, lb, nb);
+    fold_in_kernel(A, lb, nb);
+}
+
+template <int KC>
+__global__ void __launch_bounds__(256, PCR_FAST_WAVES) icp_step_fast_kernel(const StepArgs *__restrict__ Ap) {
+    fast_step_body<KC>(Ap, xcd_remap(blockIdx.x, gridDim.x), gridDim.x);
+}
+
+// Many small problems, ONE launch (BASELINE config C4: a scan set registered pair by pair -- independent fits).
+// Problem p owns the logical blocks [first[p], first[p+1]); each has its own arguments, state, tickets and partials,
+// folds and solves for itself in its own last block, and drops out of later launches once its criteria have fired.
+template <int KC>
+__global__ void __launch_bounds__(256, PCR_FAST_WAVES) icp_step_batch_kernel(const StepArgs *const *__restrict__ argv,
+                                                                             const uint32_t *__restrict__ first,
+                                                                             uint32_t count) {
+    const uint32_t b = xcd_remap(blockIdx.x, gridDim.x);
+    uint32_t lo = 0, hi = count;  // last p with first[p] <= b
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (first[mid] <= b)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    fast_step_body<KC>(argv[lo], b - first[lo], first[lo + 1] - first[lo]);
 }
 
 // Small clouds: both searches as tiled brute force (LDS-staged tiles, broadcast reads).
@@ -1199,6 +1224,81 @@ int pcr_fit_enqueue_step(pcr_fit *f) {
         return PCR_OK;
     }
     launch_step_kernels(f->ctx, f->src, f->args, f->nb, f->kc, f->partials_d, f->args_d);
+    PCR_HIP(hipGetLastError());
+    return PCR_OK;
+}
+
+struct pcr_fit_batch {
+    pcr_ctx *ctx;
+    uint32_t count, blocks, kc;
+    const StepArgs **argv_d;
+    uint32_t *first_d;
+};
+
+int pcr_fit_batch_destroy(pcr_fit_batch *b) {
+    if (!b) return PCR_OK;
+    hipSetDevice(b->ctx->device);
+    hipStreamSynchronize(b->ctx->stream);
+    if (b->argv_d) hipFree(b->argv_d);
+    if (b->first_d) hipFree(b->first_d);
+    delete b;
+    return PCR_OK;
+}
+
+int pcr_fit_batch_create(pcr_ctx *ctx, pcr_fit *const *fits, uint32_t count, pcr_fit_batch **out) {
+    PCR_REQUIRE(ctx && fits && out && count > 0, "pcr_fit_batch_create: NULL or empty argument");
+    *out = nullptr;
+    std::vector<const StepArgs *> argv(count);
+    std::vector<uint32_t> first(count + 1, 0);
+    const uint32_t kc = fits[0] ? (fits[0]->kc == 1 ? 1u : 4u) : 0u;
+    for (uint32_t i = 0; i < count; ++i) {
+        const pcr_fit *f = fits[i];
+        PCR_REQUIRE(f, "pcr_fit_batch_create: fits[%u] is NULL", i);
+        PCR_REQUIRE(f->ctx == ctx, "pcr_fit_batch_create: fits[%u] was created on another context", i);
+        for (uint32_t j = 0; j < i; ++j)
+            PCR_REQUIRE(fits[j] != f, "pcr_fit_batch_create: fits[%u] and fits[%u] are the same fit", j, i);
+        const bool fast = f->src->kind == PCR_INDEX_GRID && f->kc <= 4 && f->args.src.levels == 1 && f->args.tgt.levels == 1 &&
+                          f->args.src.v[0].shadow && f->args.tgt.v[0].shadow;
+        if (!fast || (f->kc == 1 ? 1u : 4u) != kc) {
+            set_last_error("pcr_fit_batch_create: fits[%u] cannot join this batch (needs single-level grid indices, K <= 4, "
+                           "and K = 1 either for all fits or for none)", i);
+            return PCR_E_UNSUPPORTED;
+        }
+        argv[i] = f->args_d + 1;  // the copy whose step also solves
+        first[i + 1] = first[i] + f->nb;
+    }
+    PCR_REQUIRE(first[count] > 0, "pcr_fit_batch_create: no samples in any fit");
+    PCR_HIP(hipSetDevice(ctx->device));
+    pcr_fit_batch *b = new pcr_fit_batch();
+    b->ctx = ctx;
+    b->count = count;
+    b->blocks = first[count];
+    b->kc = kc;
+    b->argv_d = nullptr;
+    b->first_d = nullptr;
+    hipError_t e = hipMalloc(&b->argv_d, sizeof(StepArgs *) * count);
+    if (e == hipSuccess) e = hipMalloc(&b->first_d, sizeof(uint32_t) * (count + 1));
+    if (e == hipSuccess) e = hipMemcpy(b->argv_d, argv.data(), sizeof(StepArgs *) * count, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(b->first_d, first.data(), sizeof(uint32_t) * (count + 1), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        set_last_error("pcr_fit_batch_create: %s", hipGetErrorString(e));
+        pcr_fit_batch_destroy(b);
+        return e == hipErrorOutOfMemory ? PCR_E_NOMEM : PCR_E_HIP;
+    }
+    *out = b;
+    return PCR_OK;
+}
+
+int pcr_fit_batch_enqueue_iteration(pcr_fit_batch *b) {
+    PCR_REQUIRE(b, "pcr_fit_batch_enqueue_iteration: NULL argument");
+    PCR_HIP(hipSetDevice(b->ctx->device));
+    ProfScope ps(b->ctx, PCR_PROF_STEP);
+    if (b->kc == 1)
+        hipLaunchKernelGGL(icp_step_batch_kernel<1>, dim3(b->blocks), dim3(256), 0, b->ctx->stream, b->argv_d,
+                           (const uint32_t *)b->first_d, b->count);
+    else
+        hipLaunchKernelGGL(icp_step_batch_kernel<4>, dim3(b->blocks), dim3(256), 0, b->ctx->stream, b->argv_d,
+                           (const uint32_t *)b->first_d, b->count);
     PCR_HIP(hipGetLastError());
     return PCR_OK;
 }

@@ -85,3 +85,55 @@ def test_batched_concurrent_fits_equal_sequential(sequence, pcr):
         assert (got["traj"] == want["traj"]).all() and (got["R"] == want["R"]).all() and (got["T"] == want["T"]).all()
     for c in ctxs:
         c.close()
+
+
+def test_one_launch_batch_equals_sequential(sequence, pcr):
+    """C4 as ONE launch per iteration (pcr_fit_batch): all pairs' fits on one context, advanced together by a single
+    kernel whose blocks are split between the problems; every fit must reproduce its sequential run bit for bit --
+    iteration count and state included (a fit that converges early idles in the remaining launches)."""
+    import time
+    scans, _ = sequence
+    pairs = [(scans[i + 1], scans[i]) for i in range(len(scans) - 1)]
+    conv = pcr.ConvergenceParams.regcfg(30)
+    ctx = pcr.Context(0)
+    fits = []
+    for s, t in pairs:
+        six, tix = pcr.Index(ctx, pcr.Cloud(ctx, s)), pcr.Index(ctx, pcr.Cloud(ctx, t))
+        U = tix.unique_sq_dist()
+        fits.append(pcr.Fit(ctx, six, tix, 4, U * 36.0, U * 4.0, conv=conv, unique_sq_dist=U, traj_cap=32))
+    eye, zero = np.eye(3).reshape(9), np.zeros(3)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    seq = [f.run(eye, zero, 30) for f in fits]
+    t_seq = time.perf_counter() - t0
+    batch = pcr.FitBatch(ctx, fits)
+    for f in fits:
+        f.reset(eye, zero)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(30):
+        batch.iterate()
+    ctx.synchronize()
+    t_bat = time.perf_counter() - t0
+    for f, want in zip(fits, seq):
+        got = f.read()
+        assert got["iterations"] == want["iterations"] and got["state"] == want["state"]
+        assert (got["traj"] == want["traj"]).all() and (got["R"] == want["R"]).all() and (got["T"] == want["T"]).all()
+    assert min(w["iterations"] for w in seq) < 30  # the case does contain fits that stop early
+    print(f"{len(fits)} fits: sequential {t_seq * 1e3:.2f} ms, one launch per iteration {t_bat * 1e3:.2f} ms")
+    batch.close()
+    ctx.close()
+
+
+def test_batch_rejects_what_it_cannot_run(sequence, pcr):
+    scans, _ = sequence
+    ctx, other = pcr.Context(0), pcr.Context(0)
+    six, tix = pcr.Index(ctx, pcr.Cloud(ctx, scans[1])), pcr.Index(ctx, pcr.Cloud(ctx, scans[0]))
+    k4 = pcr.Fit(ctx, six, tix, 4, 1e-4, 1e-4)
+    k1 = pcr.Fit(ctx, six, tix, 1, 1e-4, 1e-4)
+    foreign = pcr.Fit(other, six, tix, 4, 1e-4, 1e-4)
+    for members in ([k4, k1], [k4, foreign], [k4, k4]):  # mixed K classes; another context; the same fit twice
+        with pytest.raises(pcr.PcrError):
+            pcr.FitBatch(ctx, members)
+    other.close()
+    ctx.close()
