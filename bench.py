@@ -318,7 +318,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "valu_insts_per_launch": valu_insts, "valu_utilisation": valu_util,
-                         "kernel": f"icp_step_grid_kernel<{k if k in (1, 4, 8, 16, 32) else '>=k'}, false, {'false' if world == 1 else 'true'}>",
+                         "kernel": capi.last_step_kernel(),
                          "kernel_ms_avg": step_ms, "launches": kt["step"][1],
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "other_kernels_ms_avg": {"transform": kt_warm["transform"][0] / max(1, kt_warm["transform"][1]),

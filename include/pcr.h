@@ -63,7 +63,8 @@ const char *pcr_version(void);
  *   key 2: log2 of the brick edge (in cells) used to order the samples of a step
  *   key 3: 1 = leave K-NN query batches in the caller's order
  *   key 4: (unused: the transformed copy of the source it chose is gone -- the reverse search always moves candidates as it reads them)
- *   key 5: 1 = the ICP step never uses the fp32-filtered kernel (every candidate goes through the fp64 walk) */
+ *   key 5: 1 = neither the ICP step nor the K-NN entry points use the fp32-filtered kernels (every candidate goes
+ *          through the fp64 walk) */
 int pcr_tune(int key, int value);
 
 /* ---- context -----------------------------------------------------------------------
@@ -209,6 +210,9 @@ int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src_index, const pcr_index *tg
                    const double R[9], const double T[3], uint32_t k, double thr_fwd_sq, double thr_rev_sq,
                    uint32_t flags, double *partials_d, uint32_t *out_fwd_d, uint32_t *out_rev_d,
                    uint8_t *out_keep_d);
+/* name of the kernel the calling thread's last ICP step (single, fit or batch) was launched as -- "icp_step_fast_kernel<4>",
+ * "icp_step_grid_kernel", ... -- so that a harness can say what it measured (no reference counterpart) */
+const char *pcr_last_step_kernel(void);
 int pcr_icp_pivots(const pcr_index *src_index, const pcr_index *tgt_index, const double R[9],
                    const double T[3], double pivot_p[3], double pivot_q[3]);
 /* pcr_icp_step_d for callers that CANNOT ALLOCATE: code under HIP graph capture, tight serving loops, harnesses

@@ -76,6 +76,7 @@ SYMBOLS = {
                                  C.c_double, C.c_uint32, _vp, _vp, _vp, _vp]),
     "pcr_icp_step_noalloc_d": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _dp, _dp, C.c_uint32, C.c_double,
                                          C.c_double, C.c_uint32, _vp, _vp, _vp, _vp]),
+    "pcr_last_step_kernel": (C.c_char_p, []),
     "pcr_icp_pivots": (C.c_int, [_vp, _vp, _dp, _dp, _dp, _dp]),
     "pcr_fit_create": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, _vp,
                                  C.c_double, C.c_uint32, C.POINTER(_vp)]),
@@ -308,6 +309,10 @@ def icp_step_d(ctx, src_index, tgt_index, R, T, k, thr_fwd_sq, thr_rev_sq, parti
     _check(fn(ctx.h, src_index.h, tgt_index.h, p(sample_idx_t), sample_begin, m, _d(R), _d(T), k,
               thr_fwd_sq, thr_rev_sq, (STEP_EXACT_INDICES if exact else 0) | flags, p(partials_t),
               p(out_fwd_t), p(out_rev_t), p(out_keep_t)), "pcr_icp_step_noalloc_d" if noalloc else "pcr_icp_step_d")
+
+
+def last_step_kernel():
+    return lib().pcr_last_step_kernel().decode()
 
 
 def icp_pivots(src_index, tgt_index, R, T):

@@ -76,11 +76,10 @@ struct TopKeys {
     }
 };
 
-// The k-th smallest of N (d2, index) pairs under the total order (d2, index), by ranking: every pair is compared once;
-// of two equal pairs (only placeholders are ever equal) the earlier one ranks first.  Everything statically indexed.
+// Ranks of N (d2, index) pairs under the total order (d2, index): every pair is compared once; of two equal pairs
+// (only placeholders are ever equal) the earlier one ranks first -- the ranks are a permutation of 0..N-1.
 template <int N>
-__device__ __forceinline__ void kth_of(const double *d, const uint32_t *i, int k, double &dk, uint32_t &ik) {
-    uint32_t rank[N];
+__device__ __forceinline__ void ranks_of(const double *d, const uint32_t *i, uint32_t *rank) {
 #pragma unroll
     for (int a = 0; a < N; ++a) rank[a] = 0;
 #pragma unroll
@@ -91,6 +90,11 @@ __device__ __forceinline__ void kth_of(const double *d, const uint32_t *i, int k
             rank[a] += b_first ? 1u : 0u;
             rank[b] += b_first ? 0u : 1u;
         }
+}
+// the pair of rank k-1.  Everything statically indexed.
+template <int N>
+__device__ __forceinline__ void kth_of(const double *d, const uint32_t *i, const uint32_t *rank, int k, double &dk,
+                                       uint32_t &ik) {
     dk = d[0];
     ik = i[0];
 #pragma unroll
@@ -99,10 +103,17 @@ __device__ __forceinline__ void kth_of(const double *d, const uint32_t *i, int k
         dk = sel ? d[a] : dk;
         ik = sel ? i[a] : ik;
     }
-    if constexpr (N > 1) {
-        // (rank[0] == k-1 is the default; any other match has overwritten it)
-    }
 }
+
+// What a finished walk knows exactly: n candidates, their squared distances, indices and ranks (0 = nearest).  The ICP
+// step reads one rank; the K-NN entry points write all of the first k.
+template <int KC>
+struct FastExact {
+    double d[KC + 2];
+    uint32_t i[KC + 2];
+    uint32_t rank[KC + 2];
+    int n;
+};
 
 // One lane, one query, the 3x3x3 cells around it.
 //   g          a single-level grid WITH shadows (g.shadow != NULL)
@@ -120,14 +131,14 @@ __device__ __forceinline__ void kth_of(const double *d, const uint32_t *i, int k
 //              candidates lie below max_d2
 // Returns false when this search cannot vouch for the result (not settled within ring 1, a cell row too long for the
 // payload, a query far outside the grid, an unresolved near-tie): the caller runs lane_search instead.
-// GV, RG: GridView and Rigid in whatever address space the caller keeps them (the step kernel: the constant one,
+// TRIES: see phase 2.  GV, RG: GridView and Rigid in whatever address space the caller keeps them (the step kernel: the constant one,
 // so that every field is a scalar load at its point of use).
-template <int KC, bool XF, bool SEEDED, class GV, class RG>
+template <int KC, bool XF, bool SEEDED, int TRIES = 1, class GV, class RG>
 __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ exact_pts, double qx, double qy,
                                            double qz, double sx, double sy, double sz, double max_d2, double bound_d2,
                                            double bound_scale, double extra_margin, uint32_t delta, int k,
                                            double seed_d, uint32_t seed_i, double &out_d, uint32_t &out_i,
-                                           uint2 *rowtab, const RG *xf) {
+                                           uint2 *rowtab, const RG *xf, FastExact<KC> *all = nullptr) {
     constexpr int KP = KC + 2;
     constexpr int U = PCR_FAST_U;
     const uint32_t *__restrict__ cs = g.cs;
@@ -220,16 +231,25 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
         DIAG_ADD(24 + XF, 1);  // wave trips
         const uint32_t rem = e - p;
         uint32_t p2 = 0, e2 = 0, pb2 = 0;
-        if ((rem < (uint32_t)U) & (ri < cnt)) {
-            const uint2 row = rowtab[ri * PCR_ROW_STRIDE];
-            const uint32_t n0 = row.y & 255u, n1 = (row.y >> 8) & 255u, n2 = (row.y >> 16) & 255u, rk = row.y & 0xFF000000u;
-            const uint32_t UB = sat_add(min(T.t[KC - 1], bound_k) | ~KEY_DIST_MASK, delta);
-            const bool trim_lo = sat_add(rk, gxl_k) > UB, trim_hi = sat_add(rk, gxh_k) > UB;
-            p2 = row.x + (trim_lo ? n0 : 0u);
-            e2 = row.x + n0 + n1 + (trim_hi ? 0u : n2);
-            e2 = rk > UB ? p2 : e2;  // the whole row is provably farther than the K-th best
-            pb2 = row.x - (ri << 8);
-            ++ri;
+        // open the next row when the current one cannot fill the trip; a row that turns out to be pruned as a whole
+        // costs another try, not a trip, while tries last (TRIES: 1 where the caller brings a bound -- rows that can be
+        // pruned then never enter the table; 3 for an unbounded search -- rows are in order of slab distance, so once one
+        // is pruned most of the rest are)
+        bool want = (rem < (uint32_t)U) & (ri < cnt);
+#pragma unroll
+        for (int tries = 0; tries < TRIES; ++tries) {
+            if (want) {
+                const uint2 row = rowtab[ri * PCR_ROW_STRIDE];
+                const uint32_t n0 = row.y & 255u, n1 = (row.y >> 8) & 255u, n2 = (row.y >> 16) & 255u, rk = row.y & 0xFF000000u;
+                const uint32_t UB = sat_add(min(T.t[KC - 1], bound_k) | ~KEY_DIST_MASK, delta);
+                const bool trim_lo = sat_add(rk, gxl_k) > UB, trim_hi = sat_add(rk, gxh_k) > UB;
+                p2 = row.x + (trim_lo ? n0 : 0u);
+                e2 = row.x + n0 + n1 + (trim_hi ? 0u : n2);
+                e2 = rk > UB ? p2 : e2;  // the whole row is provably farther than the K-th best
+                pb2 = row.x - (ri << 8);
+                ++ri;
+                want = (e2 == p2) & (ri < cnt);
+            }
         }
         const uint32_t rem2 = e2 - p2, tot = rem + rem2;
         const uint32_t base2 = p2 - rem, d1 = p - pb, d2 = base2 - pb2;
@@ -264,7 +284,7 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
     // (every pair compared once); then the verification.
     constexpr int NS = SEEDED ? 1 : 0;
     double ed[KC + 1 + NS];
-    uint32_t ei[KC + 1 + NS];
+    uint32_t ei[KC + 1 + NS], rk[KC + 1 + NS];
     auto evaluate = [&](uint32_t key, double &d, uint32_t &ci) {
         d = max_d2;
         ci = PCR_NO_INDEX;
@@ -291,22 +311,38 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
     for (int j = 0; j < KC; ++j) evaluate(T.t[j], ed[NS + j], ei[NS + j]);
     double ek;
     uint32_t ik;
-    kth_of<KC + NS>(ed, ei, k, ek, ik);
+    ranks_of<KC + NS>(ed, ei, rk);
+    kth_of<KC + NS>(ed, ei, rk, k, ek, ik);
+    int n_exact = KC + NS;
     double lb = floor_d2(T.t[KC]);
     bool verified = (ek < lb) | (max_d2 <= lb);
     DIAG_LANE_ADD(18 + 4 * XF, (ok & !verified) ? 1 : 0);  // first verification failed
     if (__any(ok & !verified)) {
         DIAG_ADD(26 + XF, 1);  // wave-level second stages
         evaluate(verified ? KEY_SENTINEL : T.t[KC], ed[KC + NS], ei[KC + NS]);
+        uint32_t rk2[KC + 1 + NS];
         double ek2;
         uint32_t ik2;
-        kth_of<KC + 1 + NS>(ed, ei, k, ek2, ik2);
+        ranks_of<KC + 1 + NS>(ed, ei, rk2);
+        kth_of<KC + 1 + NS>(ed, ei, rk2, k, ek2, ik2);
         const double lb2 = floor_d2(T.t[KC + 1]);
         if (!verified) {
             ek = ek2;
             ik = ik2;
+            n_exact = KC + 1 + NS;
+#pragma unroll
+            for (int j = 0; j < KC + 1 + NS; ++j) rk[j] = rk2[j];
             verified = (ek < lb2) | (max_d2 <= lb2);
         }
+    }
+    if (all) {
+#pragma unroll
+        for (int j = 0; j < KC + 1 + NS; ++j) {
+            all->d[j] = ed[j];
+            all->i[j] = ei[j];
+            all->rank[j] = rk[j];
+        }
+        all->n = n_exact;
     }
     const bool settled = (ek < settle_b2) | (max_d2 <= settle_b2);
     DIAG_LANE_ADD(19 + 4 * XF, (ok & verified & settled) ? 0 : 1);  // handed to the fp64 walk

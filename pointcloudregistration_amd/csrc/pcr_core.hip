@@ -873,6 +873,7 @@ int pcr_index_free(pcr_index *ix) {
     hipSetDevice(ix->ctx->device);
     if (ix->pts_d) hipFree(ix->pts_d);
     if (ix->shadow_d) hipFree(ix->shadow_d);
+    if (ix->view_d) hipFree(ix->view_d);
     for (int l = 0; l < PCR_MAX_LEVELS; ++l) {
         if (ix->cs_raw_d[l]) hipFree(ix->cs_raw_d[l]);
         if (ix->cs8_d[l]) hipFree(ix->cs8_d[l]);
@@ -1302,6 +1303,8 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
                 for (int a = 0; a < 3; ++a) V.key_ext[a] = (float)((V.hi[a] - V.lo[a]) * sc * 1.000001);
             }
         }
+        BUILD_HIP(hipMalloc(&ix->view_d, sizeof(MultiView)));
+        BUILD_HIP(hipMemcpyAsync(ix->view_d, &ix->view, sizeof(MultiView), hipMemcpyHostToDevice, ctx->stream));
         BUILD_HIP(hipStreamSynchronize(ctx->stream));
         BUILD_HIP(hipGetLastError());
         ix->info.kind = kind;

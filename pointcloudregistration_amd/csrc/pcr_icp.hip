@@ -793,9 +793,32 @@ static void fit_upload_args(pcr_fit *f) {
 }
 
 // args_d: a device copy of A (set_args_kernel), what the filtered kernel reads its arguments from
+static thread_local const char *g_last_step_kernel = "none";
+
 // Returns true when the launch also folded (and, if args_d says so, solved) in the step kernel itself.
 static bool launch_step_kernels(pcr_ctx *ctx, const pcr_index *src, const StepArgs &A, uint32_t nb, uint32_t k,
                                 double *partials_d, const StepArgs *args_d) {
+    // single-level grids with fp32 shadows and K <= 4: the filtered kernel (tune 5: 1 = never, for A/B runs and tests)
+    const bool fast = src->kind == PCR_INDEX_GRID && g_tune[5] != 1 && k <= 4 && A.src.levels == 1 && A.tgt.levels == 1 &&
+                      A.src.v[0].shadow && A.tgt.v[0].shadow && args_d;
+    if (fast) {
+        g_last_step_kernel = k == 1 ? "icp_step_fast_kernel<1>" : "icp_step_fast_kernel<4>";
+        {
+            ProfScope ps(ctx, PCR_PROF_STEP);
+            if (k == 1)
+                hipLaunchKernelGGL(icp_step_fast_kernel<1>, dim3(nb), dim3(256), 0, ctx->stream, args_d);
+            else
+                hipLaunchKernelGGL(icp_step_fast_kernel<4>, dim3(nb), dim3(256), 0, ctx->stream, args_d);
+        }
+        if (A.tickets) return true;  // folded (and, with fit_inline in *args_d, solved) by the step kernel's last block
+        ProfScope ps(ctx, PCR_PROF_FOLD);
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(17), dim3(256), 0, ctx->stream, (const double *)A.block_partials, nb,
+                           partials_d);
+        return false;
+    }
+    g_last_step_kernel = src->kind != PCR_INDEX_GRID ? "icp_step_brute_kernel"
+                         : (A.src.levels > 1 || A.tgt.levels > 1) ? "icp_step_grid_kernel<multi-level>"
+                                                                  : "icp_step_grid_kernel";
 #define LAUNCH_STEP(KC)                                                                               \
     do {                                                                                              \
         if (src->kind == PCR_INDEX_GRID && (A.src.levels > 1 || A.tgt.levels > 1))                    \
@@ -857,6 +880,8 @@ static int prepare_step_args(pcr_ctx *ctx, const pcr_index *src, const pcr_index
 }
 
 extern "C" {
+
+const char *pcr_last_step_kernel(void) { return g_last_step_kernel; }
 
 int pcr_icp_pivots(const pcr_index *src, const pcr_index *tgt, const double R[9], const double T[3],
                    double pivot_p[3], double pivot_q[3]) {
@@ -1292,6 +1317,7 @@ int pcr_fit_batch_create(pcr_ctx *ctx, pcr_fit *const *fits, uint32_t count, pcr
 int pcr_fit_batch_enqueue_iteration(pcr_fit_batch *b) {
     PCR_REQUIRE(b, "pcr_fit_batch_enqueue_iteration: NULL argument");
     PCR_HIP(hipSetDevice(b->ctx->device));
+    g_last_step_kernel = b->kc == 1 ? "icp_step_batch_kernel<1>" : "icp_step_batch_kernel<4>";
     ProfScope ps(b->ctx, PCR_PROF_STEP);
     if (b->kc == 1)
         hipLaunchKernelGGL(icp_step_batch_kernel<1>, dim3(b->blocks), dim3(256), 0, b->ctx->stream, b->argv_d,

@@ -173,6 +173,7 @@ struct pcr_index {
     uint32_t *pos_of_d; // [n] original index -> position in pts_d
     uint32_t *order_d;  // [n] positions in pts_d ordered by grid brick: the processing order of "all samples"
     pcr::MultiView view;
+    pcr::MultiView *view_d;  // device copy of `view` (the filtered K-NN kernel reads the grid's description from there)
     uint32_t *cs_d[pcr::PCR_MAX_LEVELS];    // [cells+1] of every level, positions relative to the level's segment
     uint32_t *cs_raw_d[pcr::PCR_MAX_LEVELS];  // the allocations behind cs_d: cs_d - 1, [cells+3] (a zero entry either side)
     uint64_t cells[pcr::PCR_MAX_LEVELS];

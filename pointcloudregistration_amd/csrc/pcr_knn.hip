@@ -7,6 +7,7 @@
 #include <math.h>
 #include <vector>
 #include "knn_device.h"
+#include "fast_search.h"
 
 namespace pcr {
 
@@ -56,6 +57,61 @@ __global__ void __launch_bounds__(256) knn_grid_kernel(MultiView g, const double
         write_result<KC>(top, k, order_out, max_d2, out_idx + (size_t)i * k, out_d2 ? out_d2 + (size_t)i * k : nullptr);
 }
 
+// The same on a single-level grid that carries fp32 shadows: the filtered walk (fast_search.h: fp32 keys select, fp64
+// decides and verifies) and, for the rare lane it cannot vouch for, the fp64 walk above.  The grid's description is
+// read from device memory through the constant address space (scalar loads at the point of use).
+#define PCR_CONST_AS __attribute__((address_space(4)))
+template <int KC>
+__global__ void __launch_bounds__(256, 4) knn_fast_kernel(const MultiView *__restrict__ gp, const double *__restrict__ q,
+                                                          const uint32_t *__restrict__ order, uint32_t nq, int k, int order_out,
+                                                          double max_d2, uint32_t *__restrict__ out_idx,
+                                                          double *__restrict__ out_d2) {
+    const uint32_t t = xcd_remap(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
+    const bool live = t < nq;
+    const uint32_t i = live ? (order ? order[t] : t) : 0u;
+    double qx = 0, qy = 0, qz = 0;
+    if (live) {
+        qx = q[(size_t)i * 3];
+        qy = q[(size_t)i * 3 + 1];
+        qz = q[(size_t)i * 3 + 2];
+    }
+    const bool active = live && isfinite(qx) && isfinite(qy) && isfinite(qz);
+    __shared__ uint2 rowtab[9][256];
+    uint2 *my_rows = &rowtab[0][threadIdx.x];
+    const PCR_CONST_AS GridView &G = ((const PCR_CONST_AS MultiView *)(uintptr_t)gp)->v[0];
+    const double scale = 1.0 - 1.8189894035458565e-12;
+    FastExact<KC> ex;
+    double dk;
+    uint32_t ik;
+    bool done = !active;
+    if (active)
+        done = fast_ring1<KC, false, false, 3>(G, G.pts, qx, qy, qz, qx, qy, qz, max_d2, PCR_INF, scale, 0.0, G.key_delta, k, 0.0,
+                                            0u, dk, ik, my_rows, (const Rigid *)nullptr, &ex);
+    uint32_t *oi = out_idx + (size_t)i * k;
+    double *od = out_d2 ? out_d2 + (size_t)i * k : nullptr;
+    if (active & done) {  // rank r of the exact candidates goes to slot r (or k-1-r): the first k ranks fill the row
+#pragma unroll
+        for (int j = 0; j < KC + 1; ++j) {
+            if (j < ex.n && ex.rank[j] < (uint32_t)k) {
+                const uint32_t o = order_out == PCR_ORDER_DESCENDING ? (uint32_t)k - 1u - ex.rank[j] : ex.rank[j];
+                oi[o] = ex.i[j];  // (max_d2, PCR_NO_INDEX) where fewer than k candidates lie below max_d2
+                if (od) od[o] = ex.i[j] == PCR_NO_INDEX ? PCR_INF : ex.d[j];
+            }
+        }
+    }
+    if (__any(live & !(active & done))) {
+        if (live & !(active & done)) {
+            TopK<KC> top;
+            top.init(max_d2);
+            if (active) {
+                const GridView Gc = gp->v[0];
+                lane_search<KC>(Gc, gp->all, qx, qy, qz, qx, qy, qz, max_d2, scale, 0.0, top, my_rows);
+            }
+            write_result<KC>(top, k, order_out, max_d2, oi, od);
+        }
+    }
+}
+
 constexpr int BRUTE_TILE = 512;  // points per LDS tile: 16 KiB
 
 template <int KC>
@@ -96,6 +152,13 @@ template <int KC>
 static void launch_knn(pcr_ctx *ctx, const pcr_index *ix, const double *q_d, const uint32_t *qorder, uint32_t nq,
                        uint32_t k, int order, double max_d2, uint32_t *oi_d, double *od_d) {
     const uint32_t nb = (nq + 255) / 256;
+    if constexpr (KC <= 4) {
+        if (ix->kind == PCR_INDEX_GRID && ix->view.levels == 1 && ix->view.v[0].shadow && ix->view_d && g_tune[5] != 1) {
+            hipLaunchKernelGGL(knn_fast_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, (const MultiView *)ix->view_d, q_d,
+                               qorder, nq, (int)k, order, max_d2, oi_d, od_d);
+            return;
+        }
+    }
     if (ix->kind == PCR_INDEX_GRID && ix->view.levels > 1)
         hipLaunchKernelGGL((knn_grid_kernel<KC, true>), dim3(nb), dim3(256), 0, ctx->stream, ix->view, q_d, qorder, nq,
                            (int)k, order, max_d2, oi_d, od_d);

@@ -96,6 +96,8 @@ def test_filtered_kernel_equals_the_fp64_walk_bit_for_bit(pcr, ctx):
             try:
                 for mode in (1, 0):
                     pcr.lib().pcr_tune(5, mode)
+                    pcr.icp_step(ctx, six, tix, R, T, 4, U * 36.0, U * 4.0, want_outputs=False)
+                    assert pcr.last_step_kernel() == ("icp_step_grid_kernel" if mode else "icp_step_fast_kernel<4>")
                     out[mode] = [pcr.icp_step(ctx, six, tix, R, T, 4, U * 36.0, U * 4.0, exact=True),
                                  pcr.icp_step(ctx, six, tix, R, T, 4, U * 36.0, U * 4.0, exact=False),
                                  pcr.icp_step(ctx, six, tix, R, T, 1, U * 36.0, U * 4.0, exact=True),

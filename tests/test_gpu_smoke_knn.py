@@ -31,3 +31,27 @@ def test_random_volume_vs_oracle(pcr, ctx, oracle, n, nq, k):
     got, gd = ix.knn(Q, k, want_d2=True)
     assert (got == want).all()
     assert (gd == wd).all()  # squared distances bit-identical (same operation order, no FMA)
+
+
+def test_filtered_knn_equals_the_fp64_walk_bit_for_bit(pcr, ctx):
+    """pcr_knn through the fp32-filtered kernel (default on single-level grids, K <= 4) against the kernel in which every
+    candidate goes through the fp64 walk (pcr_tune key 5 = 1): indices AND squared distances, both orders, bounded and
+    unbounded, queries on, near and far from the cloud."""
+    from pointcloudregistration_amd import synth
+    src, tgt, Rm, t = synth.registration_pair(90000, 120000, 13)
+    tix = pcr.Index(ctx, pcr.Cloud(ctx, tgt), kind=pcr.INDEX_GRID)
+    U = tix.unique_sq_dist()
+    rng = np.random.default_rng(4)
+    q = np.concatenate([src @ Rm.T + t, tgt[:5000], tgt[:2000] + 3.0, rng.uniform(-2, 2, (3000, 3))])
+    for k in (1, 2, 3, 4):
+        for order in (pcr.ORDER_ASCENDING, pcr.ORDER_DESCENDING):
+            for max_d2 in (-1.0, 9.0 * U):
+                got = {}
+                try:
+                    for mode in (1, 0):
+                        pcr.lib().pcr_tune(5, mode)
+                        got[mode] = tix.knn(q, k, order=order, max_d2=max_d2, want_d2=True)
+                finally:
+                    pcr.lib().pcr_tune(5, 0)
+                assert (got[0][0] == got[1][0]).all(), (k, order, max_d2, int((got[0][0] != got[1][0]).sum()))
+                assert (got[0][1] == got[1][1]).all(), (k, order, max_d2)
