@@ -20,17 +20,19 @@
 
 namespace pcr {
 
-template <int KC>
+// MULTI: the index has nested levels; the single-level instance contains none of the level logic (and never indexes
+// the levels' descriptions at run time, which would send the whole description to every lane's scratch memory)
+template <int KC, bool MULTI>
 __device__ __forceinline__ double sq_dist_to_centroid(const MultiView &g, double x, double y, double z, int k,
                                                       double msd, uint2 *rowtab) {
     TopK<KC> top;
     top.init();
     if (isfinite(x) && isfinite(y) && isfinite(z)) {
         const double bs = 1.0 - 1.8189894035458565e-12;
-        if (g.levels > 1)
+        if constexpr (MULTI)
             multi_lane_search<KC>(g, g.all, x, y, z, x, y, z, PCR_INF, bs, 0.0, top, rowtab);
         else
-            grid_search<KC>(g.v[0], g.all, x, y, z, x, y, z, PCR_INF, bs, 0.0, top);
+            lane_search<KC>(g.v[0], g.all, x, y, z, x, y, z, PCR_INF, bs, 0.0, top, rowtab);
     }
     double c0 = x, c1 = y, c2 = z;
     int cnt = 0;
@@ -55,19 +57,23 @@ __device__ __forceinline__ double sq_dist_to_centroid(const MultiView &g, double
     return sqdist3(x, y, z, c0, c1, c2);
 }
 
-template <int KC>
+template <int KC, bool MS, bool MT>
 __global__ void __launch_bounds__(256) reject_stat_kernel(MultiView src, MultiView tgt, const double *__restrict__ pp,
-                                                          const double *__restrict__ pq, uint32_t P, int k,
-                                                          double msd, double *__restrict__ d_out) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= P) return;
+                                                          const double *__restrict__ pq, const uint32_t *__restrict__ order,
+                                                          uint32_t P, int k, double msd, double *__restrict__ d_out) {
+    // order (nullable): the pairs grouped by where their target point lies, so that a wave's 64 pairs search the same
+    // neighbourhood (pairs arrive in sample order, which says nothing about space: unsorted, every lane of a wave
+    // gathers from a different corner of both indices)
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= P) return;
+    const uint32_t i = order ? order[t] : t;
     double s[2];
     __shared__ uint2 rowtab[9][256];  // per-lane row table of the ring walk (knn_device.h), nested indices only
     // target side first, as the reference does (:74-75).  Two call sites on purpose: a run-time choice between the
     // two index arguments would make the compiler copy both (1.4 KB) into every lane's scratch memory.
     uint2 *my_rows = &rowtab[0][threadIdx.x];
-    s[0] = sq_dist_to_centroid<KC>(tgt, pq[(size_t)i * 3], pq[(size_t)i * 3 + 1], pq[(size_t)i * 3 + 2], k, msd, my_rows);
-    s[1] = sq_dist_to_centroid<KC>(src, pp[(size_t)i * 3], pp[(size_t)i * 3 + 1], pp[(size_t)i * 3 + 2], k, msd, my_rows);
+    s[0] = sq_dist_to_centroid<KC, MT>(tgt, pq[(size_t)i * 3], pq[(size_t)i * 3 + 1], pq[(size_t)i * 3 + 2], k, msd, my_rows);
+    s[1] = sq_dist_to_centroid<KC, MS>(src, pp[(size_t)i * 3], pp[(size_t)i * 3 + 1], pp[(size_t)i * 3 + 2], k, msd, my_rows);
     d_out[i] = fabs(s[0] - s[1]);  // (:77)
 }
 
@@ -180,23 +186,40 @@ extern "C" int pcr_reject_centroid_dist(pcr_ctx *ctx, const pcr_index *src, cons
     if (e == hipSuccess) e = hipMemcpyAsync(pq_d, pair_q, bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
         const uint32_t nb = (P + 255) / 256;
+        const uint32_t *qorder = nullptr;
+        if (src->kind == PCR_INDEX_GRID && P >= 2048) {
+            uint32_t *o = (uint32_t *)ctx_scratch(ctx, 4, sizeof(uint32_t) * (size_t)P);
+            if (o && coarse_query_order(ctx, tgt->view.v[0], pq_d, P, o) == PCR_OK) qorder = o;
+        }
 #define LAUNCH_STAT(KC)                                                                                              \
     do {                                                                                                             \
-        if (src->kind == PCR_INDEX_GRID)                                                                             \
-            hipLaunchKernelGGL(reject_stat_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, src->view, tgt->view,    \
-                               (const double *)pp_d, (const double *)pq_d, P, (int)msn, msd, d_d);                  \
+        if (src->kind == PCR_INDEX_GRID && src->view.levels > 1 && tgt->view.levels > 1)                            \
+            hipLaunchKernelGGL((reject_stat_kernel<KC, true, true>), dim3(nb), dim3(256), 0, ctx->stream, src->view, \
+                               tgt->view, (const double *)pp_d, (const double *)pq_d, qorder, P, (int)msn, msd, d_d); \
+        else if (src->kind == PCR_INDEX_GRID && src->view.levels > 1)                                                \
+            hipLaunchKernelGGL((reject_stat_kernel<KC, true, false>), dim3(nb), dim3(256), 0, ctx->stream, src->view, \
+                               tgt->view, (const double *)pp_d, (const double *)pq_d, qorder, P, (int)msn, msd, d_d); \
+        else if (src->kind == PCR_INDEX_GRID && tgt->view.levels > 1)                                                \
+            hipLaunchKernelGGL((reject_stat_kernel<KC, false, true>), dim3(nb), dim3(256), 0, ctx->stream, src->view, \
+                               tgt->view, (const double *)pp_d, (const double *)pq_d, qorder, P, (int)msn, msd, d_d); \
+        else if (src->kind == PCR_INDEX_GRID)                                                                        \
+            hipLaunchKernelGGL((reject_stat_kernel<KC, false, false>), dim3(nb), dim3(256), 0, ctx->stream, src->view, \
+                               tgt->view, (const double *)pp_d, (const double *)pq_d, qorder, P, (int)msn, msd, d_d); \
         else                                                                                                         \
             hipLaunchKernelGGL(reject_stat_brute_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, src->view,         \
                                tgt->view, (const double *)pp_d, (const double *)pq_d, P, (int)msn, msd, d_d);       \
     } while (0)
-        if (msn <= 4)
-            LAUNCH_STAT(4);
-        else if (msn <= 8)
-            LAUNCH_STAT(8);
-        else if (msn <= 16)
-            LAUNCH_STAT(16);
-        else
-            LAUNCH_STAT(32);
+        {
+            ProfScope ps(ctx, PCR_PROF_KNN);  // (timed with the K-NN class: two K = MSN searches per pair)
+            if (msn <= 4)
+                LAUNCH_STAT(4);
+            else if (msn <= 8)
+                LAUNCH_STAT(8);
+            else if (msn <= 16)
+                LAUNCH_STAT(16);
+            else
+                LAUNCH_STAT(32);
+        }
 #undef LAUNCH_STAT
         double *stat_d = ctx->result_d + 20;  // [mean, variance]
         hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const double *)d_d, P,
