@@ -38,18 +38,24 @@ def algorithmic_bytes_per_sample(k):
 
 def committed_traffic(kernel_prefix, points, k):
     """(HBM bytes, source file, VALU wave instructions) per launch of the step kernel from the PMC passes committed
-    under profiles/ (bytes = FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE, see tools/summarize_profile.py).  Counters cannot be collected from
-    inside this process; the figure is from `rocprofv3 --pmc` runs of this same command (tools/profile.sh)
-    and only applies to the headline workload it was collected on -- otherwise None."""
+    under profiles/ (bytes = FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE, see tools/summarize_profile.py).  Counters
+    cannot be collected from inside this process; the figure is from `rocprofv3 --pmc` runs of this same command
+    (tools/profile.sh) and is quoted ONLY for the headline workload it was collected on AND while the profile's
+    fingerprint of the device sources equals the current one -- otherwise (None, reason, None): a counter replayed
+    after the kernel changed says nothing."""
     if points != 1_000_000 or k != 4:
-        return None, None, None
+        return None, "not the profiled workload", None
     import glob
-    best = (None, None, None)
+    from pointcloudregistration_amd.stamp import kernel_sources_stamp
+    now = kernel_sources_stamp()
+    best = (None, "no profile under profiles/ matches the current device sources (" + now + ")", None)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
         try:
             with open(f) as fh:
                 d = json.load(fh)
         except (OSError, ValueError):
+            continue
+        if d.get("kernel_sources_stamp") != now:
             continue
         for name, e in d.get("kernels", {}).items():
             if name.startswith(kernel_prefix) and "hbm_traffic_bytes" in e:
@@ -293,13 +299,35 @@ def main():
                 b.synchronize()
                 ts.append(a.elapsed_time(b) * 1e-3)
             knn[f"k{kk}"] = n / float(np.median(ts[3:]))
+        # 24 + 28 K algorithmic bytes per query
+        knn["roofline"] = {f"k{kk}": {"bound": "hbm", "achieved": knn[f"k{kk}"] * (24 + 28 * kk) / 1e9, "peak": HBM_PEAK_GBS,
+                                      "unit": "GB/s", "frac": knn[f"k{kk}"] * (24 + 28 * kk) / 1e9 / HBM_PEAK_GBS,
+                                      "algorithmic_bytes_per_query": 24 + 28 * kk} for kk in (1, 4)}
+        knn["includes"] = "grouping the query batch by grid brick (two small kernels) + the search kernel; device-resident in/out"
+    reject = None
+    if rank == 0 and not args.no_knn:
+        # CRejectionCentroidDist on the kept pairs of the last iteration's transform: two K = MSN = 25 searches per pair
+        st = capi.icp_step(ctx, six, tix, R, T, k, thr_f, thr_r, exact=True)
+        kp = st["keep"].astype(bool)
+        pp = (src @ synth.rowcol(R).T + T)[kp]
+        pq = tgt[st["fwd"][kp]]
+        ctx.set_profiling(True, classes=(3,))
+        ctx.read_kernel_times()
+        rj = capi.reject_centroid_dist(ctx, six, tix, pp, pq, msn=25, msd=8.0, cdf=1.0)
+        ms = ctx.read_kernel_times()["knn"][0]
+        ctx.set_profiling(False)
+        by = (24 + 28 * 25) * 2 * len(pp)
+        reject = {"pairs": int(len(pp)), "kept": rj["kept"], "msn": 25, "stat_kernel_ms": ms,
+                  "roofline": {"bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0,
+                               "algorithmic_bytes_per_pair": (24 + 28 * 25) * 2}}
     if rank == 0:
         step_ms = kt["step"][0] / max(1, kt["step"][1])
         algo_bytes = algorithmic_bytes_per_sample(k) * m
         achieved = algo_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
         info = tix.info()
-        traffic, traffic_src, valu_insts = (committed_traffic("icp_step_grid_kernel<%d" % k, n, k) if world == 1
-                                            else (None, None, None))
+        traffic, traffic_src, valu_insts = (committed_traffic(capi.last_step_kernel(), n, k) if world == 1
+                                            else (None, "multi-GPU run", None))
         # VALU utilisation (north star): wave instructions x 4 issue cycles over the SIMD-cycles of the launch
         # (256 CUs x 4 SIMDs at the 2.4 GHz peak engine clock); instruction count from the committed PMC pass
         valu_util = (valu_insts * 4.0 / (1024 * step_ms * 1e-3 * 2.4e9)) if valu_insts and step_ms > 0 else None
@@ -325,6 +353,7 @@ def main():
                                                   "fold": kt_warm["fold"][0] / max(1, kt_warm["fold"][1]),
                                                   "measured_over": "warm-up iterations"}},
             "knn_queries_per_s": knn,
+            "reject_centroid_dist": reject,
             "index": {"build_ms_both_clouds": build_ms, "cell_size": info["cell_size"], "dims": info["dims"],
                       "mean_occupancy": info["mean_occupancy"], "cells": info["cells"], "levels": info["levels"]},
             "fit": {"kept_pairs_last": float(kept), "mse_last": float(mse), "max_abs_rot_err": rot_err,

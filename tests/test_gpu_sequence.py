@@ -137,3 +137,31 @@ def test_batch_rejects_what_it_cannot_run(sequence, pcr):
             pcr.FitBatch(ctx, members)
     other.close()
     ctx.close()
+
+
+@pytest.mark.timeout(900)
+def test_c2_sized_pair_whole_fit_vs_oracle(pcr, oracle):
+    """BASELINE config C2 at its own size: one pair of 300 000-point partial scans (the Dragon scans have 100-400 k
+    points), the WHOLE device-resident fit -- criteria on -- against the oracle's restatement of CIterativeFit::fit:
+    iteration count, convergence state, every iteration's pair count exactly, the trajectory to 1e-9."""
+    from pointcloudregistration_amd import synth
+    scans, _ = synth.scan_sequence(2, 300000, 777, step_deg=0.5)   # ~2 spacings of motion at this density
+    src, tgt = scans[1], scans[0]
+    assert min(len(src), len(tgt)) >= 250000
+    ctx = pcr.Context(0)
+    six, tix = pcr.Index(ctx, pcr.Cloud(ctx, src)), pcr.Index(ctx, pcr.Cloud(ctx, tgt))
+    U = tix.unique_sq_dist()
+    assert U == oracle.uniq_sq_dist(tgt)
+    conv = pcr.ConvergenceParams.regcfg(30)
+    got = pcr.Fit(ctx, six, tix, 4, U * 36.0, U * 4.0, conv=conv, unique_sq_dist=U, traj_cap=32).run(
+        np.eye(3).reshape(9), np.zeros(3), 30)
+    assert pcr.last_step_kernel() == "icp_step_fast_kernel<4>"
+    want = oracle.fit(src, tgt, k=4, sdft=36.0, ndft=4.0, conv=oracle.ConvParams.regcfg(30), threads=16)
+    assert got["iterations"] == want["iterations"] and got["state"] == want["state"]
+    wt = np.asarray(want["traj"])
+    assert (got["traj"][:, 13] == wt[:, 13]).all()          # kept pairs per iteration: exact
+    np.testing.assert_allclose(got["traj"][:, :12], wt[:, :12], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(got["traj"][:, 12], wt[:, 12], rtol=1e-9)
+    np.testing.assert_allclose(got["R"], want["R"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(got["T"], want["T"], rtol=0, atol=1e-9)
+    ctx.close()

@@ -15,7 +15,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 cd "$R"
 ARGS="--steps 30 --warmup 3 --no-cpu-baseline --no-knn"
-PARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-knn"
+PARGS="--steps 30 --warmup 3 --no-cpu-baseline --no-knn"
 
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
 echo "trace done"

@@ -62,7 +62,10 @@ def main():
         for (k, _d, c), v in disp.items():
             per[k][c].append(v)
 
-    out = {"tag": tag, "note": "per-launch means over the dispatches of one `bench.py --steps 5 --warmup 1` run per counter pass",
+    sys.path.insert(0, root)
+    from pointcloudregistration_amd.stamp import kernel_sources_stamp
+    out = {"tag": tag, "note": "per-launch means over the dispatches of one `bench.py --steps 30 --warmup 3` run per counter pass",
+           "kernel_sources_stamp": kernel_sources_stamp(),  # bench.py quotes these counters only while this matches
            "kernels": {}}
     for k, cs in sorted(per.items()):
         e = dict(meta[k])
@@ -76,7 +79,7 @@ def main():
         out["kernels"][k] = e
     with open(os.path.join(dst, tag + "_pmc.json"), "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
-    step = [k for k in out["kernels"] if k.startswith("icp_step_grid_kernel")]
+    step = [k for k in out["kernels"] if k.startswith("icp_step_")]
     for k in step:
         print(k, json.dumps(out["kernels"][k], indent=1))
 
