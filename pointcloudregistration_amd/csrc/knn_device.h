@@ -256,8 +256,10 @@ __device__ __forceinline__ void windowed_scan(const Pt4 *__restrict__ order, con
 //   max_d2   : candidates with d2 >= max_d2 are of no interest; the search may stop as soon as every
 //              unvisited point is at least that far
 // top must be initialised by the caller (init(), or pre-seeded with a known candidate).
-template <int KC, bool WINDOW = true, bool XF = false>
-__device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__restrict__ cand, double qx, double qy,
+// LANE_RMAX > 0: give up before a shell of a larger radius than that and return the radius of the cube scanned so far
+// (the caller continues from there -- coop_shells below).  Returns 0 when the search is finished.
+template <int KC, bool WINDOW = true, bool XF = false, int LANE_RMAX = 0>
+__device__ __forceinline__ int grid_search(const GridView &g, const Pt4 *__restrict__ cand, double qx, double qy,
                                             double qz, double sx, double sy, double sz, double max_d2,
                                             double bound_scale, double extra_margin, TopK<KC> &top,
                                             int r_start = 1, const Rigid *xf = nullptr) {
@@ -466,6 +468,9 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
             const int need = cells_needed < (double)rmax ? (int)cells_needed : rmax;
             rn = max(r + 1, min(rn, need));
         }
+        if constexpr (LANE_RMAX > 0) {
+            if (min(rn, rmax) > LANE_RMAX) return r;
+        }
         r = min(rn, rmax);  // at r == rmax the box is the whole grid and the loop ends through `all`
     }
 #ifdef PCR_DIAG
@@ -483,6 +488,7 @@ __device__ __forceinline__ void grid_search(const GridView &g, const Pt4 *__rest
     }
 #endif
 #undef DG
+    return 0;
 }
 
 
@@ -661,46 +667,210 @@ __device__ __forceinline__ bool ring1_settles(const GridView &g, double sx, doub
     return (wd < b2) | (max_d2 <= b2);
 }
 
-// The search over all levels of an index, in two passes.
+// ------------------------------------------------------------------ wave-cooperative continuation of a long search
+// One lane's value to every lane (src is wave-uniform).
+__device__ __forceinline__ uint32_t wave_bcast(uint32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ double wave_bcast(double v, int src) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)b, src), hi = __builtin_amdgcn_readlane((uint32_t)(b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+#ifndef PCR_LANE_RMAX
+#define PCR_LANE_RMAX 4  // shells up to this radius are walked by the query's own lane (at most 9 x 9 rows); measured 2..10
+#endif
+static_assert(PCR_LANE_RMAX >= 2 && PCR_LANE_RMAX <= 15, "packed four bits per level");
+#ifndef PCR_COOP_INLINE
+#define PCR_COOP_INLINE __forceinline__
+#endif
+// A query that the walk of its own 5x5x5 cells has not settled hovers far (in cells) from the level's data: what is
+// left is a ball of hundreds to thousands of rows, nearly all empty, and a lane walking them one dependent cell-table
+// load after the other runs for milliseconds while the other 63 lanes of its wave -- and, at the end of a launch, most
+// of the GPU -- wait.  Here the WHOLE WAVE finishes that one query: every argument is wave-uniform, the rows of a shell
+// are dealt out to the lanes (row i of the shell's box to lane i mod 64), each lane keeps the K best of its rows, and
+// after every shell the 64 lists are merged into the query's top-K (*shared, the same in every lane).  The shells, the
+// ball, the chords, the pruning and the stopping rule are grid_search's, so the result is the same exact K-NN.
+//   r_done: the cube of this radius around the query's cell has been scanned already.
+template <int KC, bool XF>
+__device__ PCR_COOP_INLINE void coop_shells(const GridView *gp, const Pt4 *__restrict__ cand, double qx, double qy, double qz,
+                                            double sx, double sy, double sz, double max_d2, double bound_scale,
+                                            double extra_margin, TopK<KC> *shared, int r_done, const Rigid *xf) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const Pt4 *__restrict__ order = gp->pts;
+    const uint32_t *__restrict__ cs = gp->cs;
+    const int gx = gp->g[0], gy = gp->g[1], gz = gp->g[2];
+    const double h = gp->h, inv_h = gp->inv_h, lox = gp->lo[0], loy = gp->lo[1], loz = gp->lo[2];
+    const int cx = cell_coord(sx, lox, inv_h, gx), cy = cell_coord(sy, loy, inv_h, gy), cz = cell_coord(sz, loz, inv_h, gz);
+    const double margin = gp->margin + extra_margin + 9.094947017729282e-13 * (fabs(sx) + fabs(sy) + fabs(sz));
+    double ox = fmax(fmax(lox - sx, sx - gp->hi[0]), 0.0) - margin;
+    double oy = fmax(fmax(loy - sy, sy - gp->hi[1]), 0.0) - margin;
+    double oz = fmax(fmax(loz - sz, sz - gp->hi[2]), 0.0) - margin;
+    ox = ox > 0.0 ? ox : 0.0;
+    oy = oy > 0.0 ? oy : 0.0;
+    oz = oz > 0.0 ? oz : 0.0;
+    const double ox2 = ox * ox, oy2 = oy * oy, oz2 = oz * oz;
+    TopK<KC> top = *shared;
+    int px0 = max(cx - r_done, 0), px1 = min(cx + r_done, gx - 1);
+    int py0 = max(cy - r_done, 0), py1 = min(cy + r_done, gy - 1);
+    int pz0 = max(cz - r_done, 0), pz1 = min(cz + r_done, gz - 1);
+    const int rmax = max(max(gx, gy), gz);
+    const double inv_bs = 1.0 / bound_scale;
+    int r = r_done;
+    for (;;) {
+        // next radius (grid_search's rule): double, but never past what the ball of everything that can still matter needs
+        {
+            const double reach2 = fmin(top.worst_d(), max_d2);
+            int rn = 2 * r;
+            if (reach2 < PCR_INF) {
+                const double cells_needed = (sqrt(reach2 * inv_bs) + margin) * inv_h + 2.0;
+                const int need = cells_needed < (double)rmax ? (int)cells_needed : rmax;
+                rn = max(r + 1, min(rn, need));
+            }
+            r = min(rn, rmax);
+        }
+        const int x0 = max(cx - r, 0), x1 = min(cx + r, gx - 1);
+        const int y0 = max(cy - r, 0), y1 = min(cy + r, gy - 1);
+        const int z0 = max(cz - r, 0), z1 = min(cz + r, gz - 1);
+        const int ny = y1 - y0 + 1;
+        const uint32_t nrows = (uint32_t)ny * (uint32_t)(z1 - z0 + 1);
+        // the lane's own list starts as K copies of the query's K-th best: whatever enters it beats that
+        TopK<KC> mine;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            mine.d[j] = top.worst_d();
+            mine.idx[j] = PCR_NO_INDEX;
+        }
+        double wd = mine.worst_d();
+        uint32_t wi = mine.worst_i();
+        for (uint32_t row = (uint32_t)lane; row < nrows; row += 64u) {
+            const uint32_t qz_i = row / (uint32_t)ny;  // row = (rz - z0) * ny + (ry - y0)
+            const int rz = z0 + (int)qz_i, ry = y0 + (int)(row - qz_i * (uint32_t)ny);
+            const double dz = slab_gap(sz, loz, rz, h, margin), dy = slab_gap(sy, loy, ry, h, margin);
+            const double rem = fmin(wd, max_d2) * inv_bs - dz * dz - dy * dy;
+            if (!(rem >= 0.0)) continue;
+            const double w = ball_half_width(rem) + margin;
+            const double lo_f = (sx - w - lox) * inv_h - 1.0, hi_f = (sx + w - lox) * inv_h + 1.0;
+            const bool inner = (ry >= py0) & (ry <= py1) & (rz >= pz0) & (rz <= pz1);
+            const size_t base = ((size_t)rz * gy + ry) * gx;
+#pragma unroll 1
+            for (int seg = 0; seg < 2; ++seg) {
+                int xs = seg == 0 ? x0 : px1 + 1, xe = seg == 0 ? (inner ? px0 - 1 : x1) : x1;
+                if ((seg == 1) & !inner) break;
+                if (xs > xe) continue;
+                const double lo_c = fmin(fmax(lo_f, (double)xs), (double)xe + 1.0);
+                const double hi_c = fmax(fmin(hi_f, (double)xe), (double)xs - 1.0);
+                xs = (int)lo_c;
+                xe = (int)hi_c;
+                if (xs > xe) continue;
+                const uint32_t p = cs[base + xs], e = cs[base + xe + 1];
+                if (e - p > PCR_LONG_RANGE && e > p) {
+                    windowed_scan<KC, XF>(order, cand, p, e, qx, qy, qz, sx, margin, bound_scale, mine, wd, wi, xf);
+                } else {
+                    for (uint32_t i = p; i < e; ++i) {
+                        const Pt4 c = cand[i];
+                        const double d = cand_d2<XF>(xf, qx, qy, qz, c);
+                        const uint32_t ci = (uint32_t)c.w;
+                        if (better(d, ci, wd, wi)) {
+                            mine.insert(d, ci);
+                            wd = mine.worst_d();
+                            wi = mine.worst_i();
+                        }
+                    }
+                }
+            }
+        }
+        // ---- merge: K rounds of "the best head of the 64 lists" ----
+        if (__any(mine.idx[0] != PCR_NO_INDEX)) {
+#pragma unroll 1
+            for (int k = 0; k < KC; ++k) {
+                double d = mine.d[0];
+                uint32_t i = mine.idx[0];
+#pragma unroll
+                for (int m = 32; m > 0; m >>= 1) {
+                    const double od = __shfl_xor(d, m, 64);
+                    const uint32_t oi = (uint32_t)__shfl_xor((int)i, m, 64);
+                    const bool take = better(od, oi, d, i);
+                    d = take ? od : d;
+                    i = take ? oi : i;
+                }
+                if (i == PCR_NO_INDEX) break;  // (uniform) nothing real is left in any list
+                if ((mine.idx[0] == i) & (mine.d[0] == d)) {  // the winner's list moves up
+#pragma unroll
+                    for (int j = 0; j + 1 < KC; ++j) {
+                        mine.d[j] = mine.d[j + 1];
+                        mine.idx[j] = mine.idx[j + 1];
+                    }
+                    mine.d[KC - 1] = PCR_INF;
+                    mine.idx[KC - 1] = PCR_NO_INDEX;
+                }
+                if (better(d, i, top.worst_d(), top.worst_i())) top.insert(d, i);
+            }
+        }
+        // ---- can anything outside the scanned box still matter? (grid_search's rule) ----
+        const bool all = (x0 == 0) & (x1 == gx - 1) & (y0 == 0) & (y1 == gy - 1) & (z0 == 0) & (z1 == gz - 1);
+        if (all) break;
+        double b2 = box_bound2(*gp, sx, sy, sz, margin, ox2, oy2, oz2, x0, x1, y0, y1, z0, z1);
+        b2 *= bound_scale;
+        if (top.worst_d() < b2 || max_d2 <= b2) break;
+        px0 = x0;
+        px1 = x1;
+        py0 = y0;
+        py1 = y1;
+        pz0 = z0;
+        pz1 = z1;
+        if (r >= rmax) break;  // (the box was the whole grid: `all` has caught it; belt and braces)
+    }
+    *shared = top;
+}
+
+// The search over all levels of an index, in three passes.
 //   1. The 3x3x3 walk on every level that can hold a better point.  A level the query lies outside of is entered
 //      at its cell nearest to the query.  Cheap, and afterwards the K-th distance is finite for all but the
 //      strangest queries.
-//   2. The levels that walk did not settle are completed with the shell search, whose reach is now bounded by what
-//      the OTHER levels found: a query in the hole a finer level left in a coarse one does not wander through the
-//      hole looking for K points of that level.
-// Order in both passes: the levels whose box holds the query, finest first (that is where the nearest points are),
+//   2. The levels that walk did not settle are continued with the shell search up to a radius of PCR_LANE_RMAX cells;
+//      its reach is bounded by what the OTHER levels found: a query in the hole a finer level left in a coarse one
+//      does not wander through the hole looking for K points of that level.
+//   3. The few queries that even that leaves open (hovering many cells away from a fine level's data) are finished
+//      one at a time by the whole wave (coop_shells).
+// Order in every pass: the levels whose box holds the query, finest first (that is where the nearest points are),
 // then the others from coarse to fine -- the boxes are nested, so that is by increasing distance -- each skipped
 // once its whole box is provably farther than the current K-th best.  One call site per pass (2 x levels slots).
 // Exact: every level is searched exactly against the running top-K, and the levels partition the cloud.
-template <int KC, bool XF = false>
-__device__ __forceinline__ void multi_lane_search(const MultiView &M, const Pt4 *__restrict__ cand_all, double qx, double qy,
-                                                  double qz, double sx, double sy, double sz, double max_d2,
+// Called by ALL lanes of a wave (pass 3 shuffles); `active`: this lane has a query.  M_mem, xf_mem: the index's description
+// and (R,T) in DEVICE memory -- M and *xf may live in kernel arguments and registers, whose address cannot be handed
+// to the cooperative pass (not inlined) without the compiler copying all of it to every lane's scratch memory.
+// COOP = false: no pass 3 (pass 2 runs the shell search to its end in the lane; any subset of lanes may call).
+template <int KC, bool XF = false, bool COOP = true>
+__device__ __forceinline__ void multi_lane_search(const MultiView &M, const MultiView *M_mem, const Pt4 *__restrict__ cand_all, bool active, double qx,
+                                                  double qy, double qz, double sx, double sy, double sz, double max_d2,
                                                   double bound_scale, double extra_margin, TopK<KC> &top, uint2 *rowtab,
-                                                  const Rigid *xf = nullptr) {
+                                                  const Rigid *xf = nullptr, const Rigid *xf_mem = nullptr) {
     const int L = M.levels;
     const double qmargin = extra_margin + 9.094947017729282e-13 * (fabs(sx) + fabs(sy) + fabs(sz));
     uint32_t holds = 0, open = 0;
-    for (int it = 0; it < 2 * L; ++it) {
-        const int l = it < L ? L - 1 - it : it - L;
-        const GridView &g = M.v[l];
-        bool go;
-        if (it < L) {
-            const double pad = 2.0 * g.h;  // a query a couple of cells outside is as good as inside
-            go = (l == 0) | ((sx >= g.lo[0] - pad) & (sx <= g.hi[0] + pad) & (sy >= g.lo[1] - pad) & (sy <= g.hi[1] + pad) &
-                             (sz >= g.lo[2] - pad) & (sz <= g.hi[2] + pad));
-            holds |= go ? 1u << l : 0u;
-        } else {
-            const double b2 = level_box_dist2(g, sx, sy, sz, g.margin + qmargin) * bound_scale;
-            go = !((holds >> l) & 1u) & !((top.worst_d() < b2) | (max_d2 <= b2));
+    if (active)
+        for (int it = 0; it < 2 * L; ++it) {
+            const int l = it < L ? L - 1 - it : it - L;
+            const GridView &g = M.v[l];
+            bool go;
+            if (it < L) {
+                const double pad = 2.0 * g.h;  // a query a couple of cells outside is as good as inside
+                go = (l == 0) | ((sx >= g.lo[0] - pad) & (sx <= g.hi[0] + pad) & (sy >= g.lo[1] - pad) & (sy <= g.hi[1] + pad) &
+                                 (sz >= g.lo[2] - pad) & (sz <= g.hi[2] + pad));
+                holds |= go ? 1u << l : 0u;
+            } else {
+                const double b2 = level_box_dist2(g, sx, sy, sz, g.margin + qmargin) * bound_scale;
+                go = !((holds >> l) & 1u) & !((top.worst_d() < b2) | (max_d2 <= b2));
+            }
+            if (go) {
+                DIAG_LANE_ADD(8 * (KC == 1) + 5, 1);  // ring walks
+                const bool settled = ring1_pruned<KC, XF>(g, cand_all + (g.pts - M.all), qx, qy, qz, sx, sy, sz, max_d2,
+                                                          bound_scale, extra_margin, top, rowtab, xf);
+                open |= settled ? 0u : 1u << l;
+            }
         }
-        if (go) {
-            DIAG_LANE_ADD(8 * (KC == 1) + 5, 1);  // ring walks
-            const bool settled = ring1_pruned<KC, XF>(g, cand_all + (g.pts - M.all), qx, qy, qz, sx, sy, sz, max_d2,
-                                                      bound_scale, extra_margin, top, rowtab, xf);
-            open |= settled ? 0u : 1u << l;
-        }
-    }
-    if (__any(open != 0))
+    if (__any(open != 0)) {
+        uint32_t left = 0;
         for (int it = 0; it < 2 * L; ++it) {
             const int l = it < L ? L - 1 - it : it - L;
             const GridView &g = M.v[l];
@@ -710,10 +880,43 @@ __device__ __forceinline__ void multi_lane_search(const MultiView &M, const Pt4 
                 go = !((top.worst_d() < b2) | (max_d2 <= b2)) &&
                      !ring1_settles(g, sx, sy, sz, g.margin + qmargin, bound_scale, top.worst_d(), max_d2);
             }
-            if (go)
-                grid_search<KC, true, XF>(g, cand_all + (g.pts - M.all), qx, qy, qz, sx, sy, sz, max_d2, bound_scale,
-                                          extra_margin, top, 2, xf);
+            if (go) {
+                const int r_done = grid_search<KC, true, XF, COOP ? PCR_LANE_RMAX : 0>(
+                    g, cand_all + (g.pts - M.all), qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, 2, xf);
+                left |= (uint32_t)r_done << (4 * l);  // (PCR_LANE_RMAX <= 15, at most 6 levels)
+            }
         }
+        // ---- pass 3: one unfinished query at a time, by the whole wave ----
+        unsigned long long pending = COOP ? __ballot(left != 0) : 0ull;
+        while (pending) {
+            const int src = __ffsll(pending) - 1;
+            pending &= pending - 1ull;
+            DIAG_ADD(8 * (KC == 1) + 6, 1);  // cooperative searches
+            const uint32_t u_left = wave_bcast(left, src), u_holds = wave_bcast(holds, src);
+            const double uqx = wave_bcast(qx, src), uqy = wave_bcast(qy, src), uqz = wave_bcast(qz, src);
+            const double usx = XF ? wave_bcast(sx, src) : uqx, usy = XF ? wave_bcast(sy, src) : uqy,
+                         usz = XF ? wave_bcast(sz, src) : uqz;
+            const double uqm = extra_margin + 9.094947017729282e-13 * (fabs(usx) + fabs(usy) + fabs(usz));
+            TopK<KC> shared;
+#pragma unroll
+            for (int j = 0; j < KC; ++j) {
+                shared.d[j] = wave_bcast(top.d[j], src);
+                shared.idx[j] = wave_bcast(top.idx[j], src);
+            }
+            for (int it = 0; it < 2 * L; ++it) {
+                const int l = it < L ? L - 1 - it : it - L;
+                const int r_done = (int)((u_left >> (4 * l)) & 15u);
+                if (!((r_done != 0) & (((u_holds >> l) & 1u) == (it < L ? 1u : 0u)))) continue;
+                const GridView &g = M.v[l];
+                // other levels may have shrunk the K-th distance since this one was left open
+                const double b2 = level_box_dist2(g, usx, usy, usz, g.margin + uqm) * bound_scale;
+                if ((shared.worst_d() < b2) | (max_d2 <= b2)) continue;
+                coop_shells<KC, XF>(&M_mem->v[l], cand_all + (g.pts - M.all), uqx, uqy, uqz, usx, usy, usz, max_d2, bound_scale,
+                                    extra_margin, &shared, r_done, xf_mem);
+            }
+            if ((int)(threadIdx.x & 63u) == src) top = shared;
+        }
+    }
 }
 
 // Brute-force scan of one LDS tile (all lanes read the same address: LDS broadcast).
@@ -741,6 +944,15 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nb) {
     const uint32_t xcd = bid & 7u, slot = bid >> 3;
     const uint32_t start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return start + slot;
+}
+
+// The same within chunks of `chunk` consecutive logical blocks (about what the GPU runs at once): every XCD works on
+// an eighth of EVERY chunk.  For clouds whose cost per block varies along the processing order (nested levels: the
+// fine levels' blocks take ten times as long as the coarse ones') -- with the plain remap the XCD that draws the
+// expensive end of the order finishes long after the others.
+__device__ __forceinline__ uint32_t xcd_remap_chunked(uint32_t bid, uint32_t nb, uint32_t chunk = 1024u) {
+    const uint32_t c0 = (bid / chunk) * chunk;
+    return c0 + xcd_remap(bid - c0, min(chunk, nb - c0));
 }
 
 }  // namespace pcr

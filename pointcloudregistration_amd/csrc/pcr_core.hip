@@ -1261,6 +1261,10 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
             B.counts_raw = B.counts_d = nullptr;
             B.counts_cap = 0;
             M.levels = l + 1;
+            if (getenv("PCR_TRACE_BUILD"))
+                fprintf(stderr, "[pcr] level %d: n=%u h=%.6g dims=%dx%dx%d cells=%llu occupied=%llu largest=%llu box=[%.3g %.3g %.3g]-[%.3g %.3g %.3g]\n",
+                        l, n_l, B.h, B.G.g[0], B.G.g[1], B.G.g[2], (unsigned long long)B.cells, B.stats_h[0], B.stats_h[1],
+                        lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]);
             // processing order of "all samples": by grid brick, so that a wave's 64 queries share a small box
             BUILD_RC(brick_order(ctx, V, V.pts, nullptr, n_l, ix->order_d + off, true, off));
             BUILD_HIP(hipStreamSynchronize(ctx->stream));

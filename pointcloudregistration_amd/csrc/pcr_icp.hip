@@ -16,7 +16,10 @@
 #include "fast_search.h"
 #include "solve_core.h"
 #ifndef PCR_STEP_WAVES
-#define PCR_STEP_WAVES 5
+#define PCR_STEP_WAVES 4
+#endif
+#ifndef PCR_MULTI_WAVES
+#define PCR_MULTI_WAVES 3  // nested levels: 168 registers spill far less than 128 (16 M LiDAR iteration: 26.7 -> 17.5 ms)
 #endif
 #ifndef PCR_FAST_WAVES
 #define PCR_FAST_WAVES 4
@@ -70,6 +73,7 @@ __global__ void set_dyn_kernel(StepDyn value, StepDyn *dst) { *dst = value; }
 struct FitDev;
 struct StepArgs {
     MultiView src, tgt;
+    const MultiView *src_mem, *tgt_mem;  // the indices' own device copies of the same (pcr_index::view_d)
     const uint32_t *src_pos_of;  // original index -> position in src.pts
     const uint32_t *src_order;   // positions of src.pts in brick order (processing order of "all samples")
     const uint32_t *sample_idx;  // NULL: samples are positions [sample_begin, sample_begin+m)
@@ -238,12 +242,19 @@ __device__ __forceinline__ void fold_in_kernel(AP A, uint32_t lb, uint32_t nb) {
 // expression, so every distance is the one the reference gets from its transformed copy, :73-74): no copy is ever
 // written, an index holds no per-iteration state -- fits may share it -- and no rank of a sharded fit does work
 // proportional to the WHOLE source.
+#ifdef PCR_BLOCK_TIMES
+// timing build only (never shipped): start/end of every block of the last grid-kernel launch, 100 MHz ticks
+__device__ unsigned long long g_block_times[2 * 65536];
+#endif
 template <int KC, bool MULTI>
-__global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(StepArgs A) {
+__global__ void __launch_bounds__(256, MULTI ? PCR_MULTI_WAVES : PCR_STEP_WAVES) icp_step_grid_kernel(StepArgs A) {
     const StepDyn *__restrict__ dynp = A.dyn;
     if (dynp->done) return;  // uniform over the grid
     const StepDyn D = *dynp;
-    const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t lb = MULTI ? xcd_remap_chunked(blockIdx.x, gridDim.x) : xcd_remap(blockIdx.x, gridDim.x);
+#ifdef PCR_BLOCK_TIMES
+    if (threadIdx.x == 0 && lb < 65536u) g_block_times[2 * lb] = wall_clock64();
+#endif
     const uint32_t t = lb * 256u + threadIdx.x;
     const bool live = t < A.m;
     double acc[17];
@@ -271,13 +282,12 @@ __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(Step
     top.init(fmax_d2);
     __shared__ uint2 rowtab[9][256];  // per-lane row table of the ring walk (knn_device.h)
     uint2 *my_rows = &rowtab[0][threadIdx.x];
-    if (fin) {
-        if constexpr (MULTI)
-            multi_lane_search<KC>(A.tgt, A.tgt.all, px, py, pz, px, py, pz, fmax_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
-                                  my_rows);
-        else
-            lane_search<KC>(A.tgt.v[0], A.tgt.all, px, py, pz, px, py, pz, fmax_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
-                            my_rows);
+    if constexpr (MULTI) {  // (every lane calls: the level search finishes its longest queries wave-cooperatively)
+        multi_lane_search<KC>(A.tgt, A.tgt_mem, A.tgt.all, fin, px, py, pz, px, py, pz, fmax_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
+                              my_rows);
+    } else if (fin) {
+        lane_search<KC>(A.tgt.v[0], A.tgt.all, px, py, pz, px, py, pz, fmax_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
+                        my_rows);
     }
     double dF;
     uint32_t j;
@@ -303,13 +313,12 @@ __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(Step
     rt.d[0] = dF;
     rt.idx[0] = orig;
     const bool rev_active = need_rev && isfinite(sx) && isfinite(sy) && isfinite(sz);
-    if (rev_active) {
-        if constexpr (MULTI)
-            multi_lane_search<1, true>(A.src, A.src.all, qx, qy, qz, sx, sy, sz, PCR_INF, D.rev_bound_scale, D.rev_extra_margin,
-                                       rt, my_rows, &D.M);
-        else
-            lane_search<1, true>(A.src.v[0], A.src.all, qx, qy, qz, sx, sy, sz, PCR_INF, D.rev_bound_scale, D.rev_extra_margin,
-                                 rt, my_rows, &D.M);
+    if constexpr (MULTI) {
+        multi_lane_search<1, true>(A.src, A.src_mem, A.src.all, rev_active, qx, qy, qz, sx, sy, sz, PCR_INF, D.rev_bound_scale,
+                                   D.rev_extra_margin, rt, my_rows, &D.M, &dynp->M);
+    } else if (rev_active) {
+        lane_search<1, true>(A.src.v[0], A.src.all, qx, qy, qz, sx, sy, sz, PCR_INF, D.rev_bound_scale, D.rev_extra_margin,
+                             rt, my_rows, &D.M);
     }
     uint32_t r = PCR_NO_INDEX;
     bool keep = false;
@@ -326,6 +335,9 @@ __global__ void __launch_bounds__(256, PCR_STEP_WAVES) icp_step_grid_kernel(Step
         if (A.out_keep) A.out_keep[slot] = keep ? 1 : 0;
     }
     block_reduce17(acc, A.block_partials, lb, gridDim.x);
+#ifdef PCR_BLOCK_TIMES
+    if (threadIdx.x == 0 && lb < 65536u) g_block_times[2 * lb + 1] = wall_clock64();
+#endif
     fold_in_kernel(&A, lb, gridDim.x);
 }
 
@@ -867,6 +879,8 @@ static int prepare_step_args(pcr_ctx *ctx, const pcr_index *src, const pcr_index
     memset(&A, 0, sizeof A);
     A.src = src->view;
     A.tgt = tgt->view;
+    A.src_mem = src->view_d;
+    A.tgt_mem = tgt->view_d;
     A.src_pos_of = src->pos_of_d;
     A.src_order = src->order_d;
     A.sample_idx = sample_idx_d;
@@ -1378,6 +1392,11 @@ int pcr_fit_read(pcr_fit *f, double R[9], double T[3], uint32_t *iterations, int
 
 }  // extern "C"
 
+#ifdef PCR_BLOCK_TIMES
+extern "C" int pcr_diag_block_times(unsigned long long *out, unsigned n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pcr::g_block_times), sizeof(unsigned long long) * 2 * n) == hipSuccess ? 0 : -2;
+}
+#endif
 #ifdef PCR_DIAG
 extern "C" int pcr_diag_read_icp(unsigned long long out[32], int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcr::g_diag), sizeof(unsigned long long) * 32) != hipSuccess) return -2;

@@ -28,11 +28,11 @@ __device__ __forceinline__ void write_result(const TopK<KC> &top, int k, int ord
 // One lane per query, pruned ring walk (knn_device.h).
 // order (nullable): processing order of the queries (by grid brick), results go to the query's own row.
 template <int KC, bool MULTI>
-__global__ void __launch_bounds__(256) knn_grid_kernel(MultiView g, const double *__restrict__ q,
+__global__ void __launch_bounds__(256) knn_grid_kernel(MultiView g, const MultiView *__restrict__ g_mem, const double *__restrict__ q,
                                                        const uint32_t *__restrict__ order, uint32_t nq, int k,
                                                        int order_out, double max_d2, uint32_t *__restrict__ out_idx,
                                                        double *__restrict__ out_d2) {
-    const uint32_t t = xcd_remap(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
+    const uint32_t t = (MULTI ? xcd_remap_chunked(blockIdx.x, gridDim.x) : xcd_remap(blockIdx.x, gridDim.x)) * 256u + threadIdx.x;
     const bool live = t < nq;
     const uint32_t i = live ? (order ? order[t] : t) : 0u;
     double qx = 0, qy = 0, qz = 0;
@@ -45,13 +45,12 @@ __global__ void __launch_bounds__(256) knn_grid_kernel(MultiView g, const double
     TopK<KC> top;
     top.init(max_d2);
     __shared__ uint2 rowtab[9][256];
-    if (active) {
-        if constexpr (MULTI)
-            multi_lane_search<KC>(g, g.all, qx, qy, qz, qx, qy, qz, max_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
-                                  &rowtab[0][threadIdx.x]);
-        else
-            lane_search<KC>(g.v[0], g.all, qx, qy, qz, qx, qy, qz, max_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
-                            &rowtab[0][threadIdx.x]);
+    if constexpr (MULTI) {  // (every lane calls: see multi_lane_search)
+        multi_lane_search<KC, false, (KC <= 8)>(g, g_mem, g.all, active, qx, qy, qz, qx, qy, qz, max_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
+                              &rowtab[0][threadIdx.x]);
+    } else if (active) {
+        lane_search<KC>(g.v[0], g.all, qx, qy, qz, qx, qy, qz, max_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
+                        &rowtab[0][threadIdx.x]);
     }
     if (live)
         write_result<KC>(top, k, order_out, max_d2, out_idx + (size_t)i * k, out_d2 ? out_d2 + (size_t)i * k : nullptr);
@@ -160,10 +159,10 @@ static void launch_knn(pcr_ctx *ctx, const pcr_index *ix, const double *q_d, con
         }
     }
     if (ix->kind == PCR_INDEX_GRID && ix->view.levels > 1)
-        hipLaunchKernelGGL((knn_grid_kernel<KC, true>), dim3(nb), dim3(256), 0, ctx->stream, ix->view, q_d, qorder, nq,
+        hipLaunchKernelGGL((knn_grid_kernel<KC, true>), dim3(nb), dim3(256), 0, ctx->stream, ix->view, (const MultiView *)ix->view_d, q_d, qorder, nq,
                            (int)k, order, max_d2, oi_d, od_d);
     else if (ix->kind == PCR_INDEX_GRID)
-        hipLaunchKernelGGL((knn_grid_kernel<KC, false>), dim3(nb), dim3(256), 0, ctx->stream, ix->view, q_d, qorder, nq,
+        hipLaunchKernelGGL((knn_grid_kernel<KC, false>), dim3(nb), dim3(256), 0, ctx->stream, ix->view, (const MultiView *)ix->view_d, q_d, qorder, nq,
                            (int)k, order, max_d2, oi_d, od_d);
     else
         hipLaunchKernelGGL(knn_brute_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, ix->pts_d, ix->n, q_d, nq,

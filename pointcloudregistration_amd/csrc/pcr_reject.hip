@@ -27,11 +27,12 @@ __device__ __forceinline__ double sq_dist_to_centroid(const MultiView &g, double
                                                       double msd, uint2 *rowtab) {
     TopK<KC> top;
     top.init();
-    if (isfinite(x) && isfinite(y) && isfinite(z)) {
+    {
+        const bool fin = isfinite(x) && isfinite(y) && isfinite(z);
         const double bs = 1.0 - 1.8189894035458565e-12;
-        if constexpr (MULTI)
-            multi_lane_search<KC>(g, g.all, x, y, z, x, y, z, PCR_INF, bs, 0.0, top, rowtab);
-        else
+        if constexpr (MULTI)  // (lists of up to 32 entries: no wave-cooperative pass, whose merge is sized for a handful)
+            multi_lane_search<KC, false, false>(g, nullptr, g.all, fin, x, y, z, x, y, z, PCR_INF, bs, 0.0, top, rowtab);
+        else if (fin)
             lane_search<KC>(g.v[0], g.all, x, y, z, x, y, z, PCR_INF, bs, 0.0, top, rowtab);
     }
     double c0 = x, c1 = y, c2 = z;

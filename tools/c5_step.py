@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Config C5 as a command the profiler can wrap: LiDAR-like 16 M x 16 M pair, 30 % outliers, nested
+index levels; runs `--steps` production-mode ICRP iterations' worth of step launches over all samples and prints one
+JSON line (kernel time per launch by HIP events on the context's stream).
+    python3 tools/c5_step.py [--n 16000000] [--steps 5] [--outliers 0.3]
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=16_000_000)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--outliers", type=float, default=0.3)
+    ap.add_argument("--k", type=int, default=4)
+    ap.add_argument("--occupancy", type=float, default=0.0, help="index target occupancy (0: library default)")
+    a = ap.parse_args()
+    from pointcloudregistration_amd import capi as pcr, synth
+    src, tgt, Rm, t = synth.lidar_pair(a.n, 516, outlier_frac=a.outliers)
+    ctx = pcr.Context(0)
+    six = pcr.Index(ctx, pcr.Cloud(ctx, src), target_occupancy=a.occupancy)
+    tix = pcr.Index(ctx, pcr.Cloud(ctx, tgt), target_occupancy=a.occupancy)
+    U = tix.unique_sq_dist()
+    R, T = synth.colmajor(Rm), t
+    pcr.icp_step(ctx, six, tix, R, T, a.k, U * 36.0, U * 4.0, exact=False, want_outputs=False)   # warm-up
+    ctx.set_profiling(True, classes=[1])
+    for _ in range(a.steps):
+        out = pcr.icp_step(ctx, six, tix, R, T, a.k, U * 36.0, U * 4.0, exact=False, want_outputs=False)
+    ms, cnt = ctx.read_kernel_times()["step"]
+    si, ti = six.info(), tix.info()
+    print(json.dumps({"workload": f"C5 lidar {a.n}x{a.n}, {a.outliers:.0%} outliers, K={a.k}", "step_ms": ms / max(cnt, 1),
+                      "launches": cnt, "samples_per_s": a.n / (ms / max(cnt, 1) * 1e-3), "kept_pairs": float(out["partials"][0]),
+                      "kernel": pcr.last_step_kernel(),
+                      "src_index": {k: si[k] for k in ("levels", "cells", "occupied_cells", "device_bytes")},
+                      "tgt_index": {k: ti[k] for k in ("levels", "cells", "occupied_cells", "device_bytes")}}))
+
+
+if __name__ == "__main__":
+    main()
