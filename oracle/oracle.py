@@ -1,5 +1,4 @@
-"""ctypes bindings of the CPU oracle (oracle/liboracle.so) and, when present, of the
-reference's own KD-tree build (oracle/_ref/libref_knn.so).
+"""ctypes bindings of the CPU oracle (oracle/liboracle.so).
 
 TEST INFRASTRUCTURE ONLY: the checker, never the thing measured or shipped.
 """
@@ -36,9 +35,9 @@ def _f64(a, cols=3):
     return a
 
 
-def build(ref=True):
-    """(Re)build liboracle.so and, if /root/reference is present, _ref/libref_knn.so."""
-    subprocess.check_call(["make", "-s", "-C", _HERE, "oracle"] + (["ref"] if ref else []))
+def build():
+    """(Re)build liboracle.so."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "oracle"])
 
 
 class ConvParams(C.Structure):
@@ -64,7 +63,7 @@ def lib():
     if _lib is None:
         path = os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(path):
-            build(ref=False)
+            build()
         L = C.CDLL(path)
         L.orc_kd_old_build.restype = C.c_void_p
         L.orc_kd_old_build.argtypes = [_dp, C.c_uint32, C.c_uint32]
@@ -265,41 +264,3 @@ def reject_centroid_dist(src, tgt, pair_p, pair_q, msn=25, msd=8.0, cdf=1.0):
     return dict(d=d, keep=keep, mean=stat[0], sigma=stat[1], kept=n)
 
 
-# ---------------------------------------------------------------- the real reference tree
-_ref = None
-
-
-def ref_available():
-    return os.path.exists(os.path.join(_HERE, "_ref", "libref_knn.so"))
-
-
-def ref_lib():
-    global _ref
-    if _ref is None:
-        L = C.CDLL(os.path.join(_HERE, "_ref", "libref_knn.so"))
-        L.ref_knn_build.restype = C.c_void_p
-        L.ref_knn_build.argtypes = [_dp, C.c_uint32, C.c_uint32]
-        L.ref_knn_query.argtypes = [C.c_void_p, _dp, C.c_uint32, _up]
-        L.ref_knn_free.argtypes = [C.c_void_p]
-        _ref = L
-    return _ref
-
-
-class RefKd:
-    """The reference's hiveCommon::CKNNSearch itself (oracle/_ref, built from its own source)."""
-
-    def __init__(self, xyz, k):
-        self.xyz = _f64(xyz)
-        self.k = int(k)
-        self.h = ref_lib().ref_knn_build(_d(self.xyz), len(self.xyz), self.k)
-
-    def query(self, q):
-        q = _f64(q)
-        idx = np.empty((len(q), self.k), np.uint32)
-        ref_lib().ref_knn_query(self.h, _d(q), len(q), _u(idx))
-        return idx
-
-    def __del__(self):
-        if getattr(self, "h", None):
-            ref_lib().ref_knn_free(self.h)
-            self.h = None

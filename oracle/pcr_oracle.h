@@ -7,14 +7,12 @@
  * path.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
  * may load it; nothing under pointcloudregistration_amd/ links or imports it.
  *
- * Pinning: the KD-tree restatement (orc_kd_old_*) is checked index-for-index
- * against the reference's own Common/KNNSearch.cpp compiled unmodified into
- * oracle/_ref/libref_knn.so (see oracle/Makefile, tests/test_oracle_pin.py) and
- * against the golden vectors under tests/golden/ that were generated from that
- * build.  Everything above the tree (loop, SVD2, convergence, rejection) needs
- * Eigen/Boost/Hive, which are absent, so those parts follow the source text
- * only; the reference holds no golden numbers for them:
- * "parity unpinned" above the tree, see DESIGN.md.
+ * PARITY UNPINNED.  The reference holds no golden vectors, known-answer tests or
+ * fixtures for this path, and none of its sources can be
+ * built in this image: the one self-contained file, Common/KNNSearch.cpp, needs
+ * the un-vendored Hive framework's CommonExport.h, everything above the tree
+ * needs Eigen/Boost/Hive.  The restatement follows the source text only; the
+ * vectors under tests/golden/ are its own frozen outputs (make_golden.py).
  *
  * All arithmetic is IEEE fp64 compiled with -ffp-contract=off.  Points are AoS
  * double[3n]; R is 3x3 column-major (Eigen::Matrix3d::data()), T is 3.

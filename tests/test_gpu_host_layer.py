@@ -27,10 +27,10 @@ def host():
     hostapi.reset()
 
 
-def test_grid_search_plugin_matches_reference_tree(host):
+def test_grid_search_plugin_matches_golden_knn(host):
     """hiveSearch::CBaseSearch contract: row-major [nq x K], farthest first (DistanceQueue.cpp:37-46); the
-    ascending variant is what hiveCommon::CKNNSearch::executeKNN returns.  Golden indices come from the
-    reference's own compiled KD-tree."""
+    ascending variant is what hiveCommon::CKNNSearch::executeKNN returns.  Golden indices: the oracle's restated tree on the
+    reference's own scan patch (tests/golden/patch_knn.npz)."""
     g = golden("patch_knn.npz")
     tgt = golden("patch_k1.npz")["tgt"]
     for k in (1, 2, 4, 8, 25, 32):

@@ -1,5 +1,7 @@
-"""CPU tests of the oracle (the checker): pinned against the golden vectors produced by the reference's
-own KD-tree, against that tree itself when oracle/_ref is present, and against the brute-force definition."""
+"""CPU tests of the oracle (the checker): against the committed golden vectors and against the brute-force
+definition.  The reference holds no fixtures for this path and its sources are unbuildable in this image
+(oracle/Makefile), so the oracle is "parity unpinned": the vectors under tests/golden/ are the oracle's own
+outputs (tests/golden/make_golden.py), kept so that a change of the restatement cannot go unnoticed."""
 import os
 
 import numpy as np
@@ -11,7 +13,7 @@ CASES = ["patch_k1", "patch_k4", "cube4096_k1", "cube4096_k4", "spheres40k_k1", 
 
 
 def test_knn_known_answers(oracle):
-    """tests/golden/patch_knn.npz holds indices returned by /root/reference/Common/KNNSearch.cpp itself."""
+    """tests/golden/patch_knn.npz: K-NN indices on the reference's own scan patch (the oracle's, frozen)."""
     g = golden("patch_knn.npz")
     tgt = golden("patch_k1.npz")["tgt"]
     for k in (1, 2, 4, 8, 25, 32):
@@ -19,7 +21,7 @@ def test_knn_known_answers(oracle):
 
 
 @pytest.mark.parametrize("name", CASES)
-def test_loop_matches_reference_tree_golden(oracle, name):
+def test_loop_matches_golden(oracle, name):
     g = golden(name + ".npz")
     src, tgt = case_inputs(name, g)
     k = int(g["k"])
@@ -37,18 +39,17 @@ def test_loop_matches_reference_tree_golden(oracle, name):
     assert (fit["R"] == g["final_R"]).all() and (fit["T"] == g["final_T"]).all()
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "libref_knn.so")),
-                    reason="oracle/_ref not built (needs /root/reference)")
-@pytest.mark.parametrize("k", [1, 4, 25])
-def test_restated_tree_equals_reference_tree(oracle, k):
-    """Index-for-index, including exact-tie inputs where the answer depends on KD-tree visit order."""
-    rng = np.random.default_rng(k)
-    X = rng.random((20000, 3))
-    Q = rng.random((4000, 3)) * 1.2 - 0.1
-    assert (oracle.KdOld(X, k).query(Q) == oracle.RefKd(X, k).query(Q)).all()
-    X2 = np.round(rng.random((3000, 3)) * 8) / 8  # lattice: many exactly equidistant candidates, duplicates
+def test_restated_tree_on_exact_ties_keeps_the_visit_order_rule(oracle):
+    """Exact-tie inputs (lattice points, duplicates), where the answer depends on the KD-tree's visit order: the
+    restated tree must at least return a correct neighbour SET by distance (the order rule itself is the source
+    text's, Common/KNNSearch.cpp:79-360, and has no reference-held expected values)."""
+    rng = np.random.default_rng(4)
+    X2 = np.round(rng.random((3000, 3)) * 8) / 8
     Q2 = np.round(rng.random((1500, 3)) * 16) / 16
-    assert (oracle.KdOld(X2, k).query(Q2) == oracle.RefKd(X2, k).query(Q2)).all()
+    for k in (1, 4, 25):
+        a, ad = oracle.KdOld(X2, k).query(Q2, want_d2=True)
+        _, bd = oracle.knn_brute(X2, Q2, k)
+        assert (ad == bd).all()
 
 
 def test_tree_equals_brute_force_without_ties(oracle):
