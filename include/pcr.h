@@ -334,6 +334,20 @@ int pcr_reject_centroid_dist(pcr_ctx *ctx, const pcr_index *src_index, const pcr
                              const double *pair_p, const double *pair_q, uint32_t P, uint32_t msn, double msd,
                              double cdf, uint8_t *out_keep, double *out_d, double *out_stat);
 
+
+/* The same with the PAIRS sharded over ranks ("a second tiny all-reduce of (sum d, P) then
+ * sum (d - mean)^2"; RejectionCentroidDist.cpp:34-37 computes both over all pairs).  Each rank passes its own P
+ * pairs (P = 0 allowed) and a hook that sums a 17-double DEVICE buffer over all ranks, in place, ordered on the
+ * context's stream -- called exactly twice on every rank.  The buffer has the shape of the fit loop's partials, so
+ * pcr_allreduce_partials serves (pcr_reduce17_with_comm below, user = the pcr_comm), and so does any communicator
+ * the caller owns.  The hook returns PCR_OK or a negative status.  out_stat = {mean, sigma} over ALL ranks' pairs. */
+typedef int (*pcr_reduce17_fn)(void *user, double *buf17_d);
+int pcr_reduce17_with_comm(void *comm /* pcr_comm* */, double *buf17_d);
+int pcr_reject_centroid_dist_sharded(pcr_ctx *ctx, const pcr_index *src_index, const pcr_index *tgt_index,
+                                     const double *pair_p, const double *pair_q, uint32_t P, uint32_t msn, double msd,
+                                     double cdf, uint8_t *out_keep, double *out_d, double *out_stat,
+                                     pcr_reduce17_fn reduce, void *reduce_user);
+
 #ifdef __cplusplus
 }
 #endif

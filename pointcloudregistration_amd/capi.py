@@ -99,7 +99,11 @@ SYMBOLS = {
     "pcr_solve_rigid": (C.c_int, [_dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "pcr_reject_centroid_dist": (C.c_int, [_vp, _vp, _vp, _dp, _dp, C.c_uint32, C.c_uint32, C.c_double, C.c_double,
                                            _bp, _dp, _dp]),
+    "pcr_reject_centroid_dist_sharded": (C.c_int, [_vp, _vp, _vp, _dp, _dp, C.c_uint32, C.c_uint32, C.c_double,
+                                                   C.c_double, _bp, _dp, _dp, _vp, _vp]),
+    "pcr_reduce17_with_comm": (C.c_int, [_vp, _vp]),
 }
+REDUCE17_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)  # pcr_reduce17_fn(user, buf17_d)
 
 _lib = None
 
@@ -511,12 +515,32 @@ def solve_rigid(partials, pivot_p, pivot_q, R, T):
     return R, T, Rc, Tc, mse.value
 
 
-def reject_centroid_dist(ctx, src_index, tgt_index, pair_p, pair_q, msn=25, msd=8.0, cdf=1.0):
+def reject_centroid_dist(ctx, src_index, tgt_index, pair_p, pair_q, msn=25, msd=8.0, cdf=1.0, reduce=None):
+    """reduce: None (all pairs are here), a Comm (pairs sharded over its ranks: the library's in-stream RCCL
+    all-reduce), or a callable(ptr) that sums the 17-double device buffer at `ptr` over all ranks in place, ordered
+    on the context's stream (e.g. torch.distributed on a tensor wrapping it) and returns None/0 or a negative status."""
     pp, pq = _f64(pair_p), _f64(pair_q)
     P = len(pp)
     keep = np.empty(P, np.uint8)
     d = np.empty(P)
     stat = np.empty(2)
-    _check(lib().pcr_reject_centroid_dist(ctx.h, src_index.h, tgt_index.h, _d(pp), _d(pq), P, msn, msd, cdf, _b(keep),
-                                          _d(d), _d(stat)), "pcr_reject_centroid_dist")
+    if reduce is None:
+        _check(lib().pcr_reject_centroid_dist(ctx.h, src_index.h, tgt_index.h, _d(pp), _d(pq), P, msn, msd, cdf,
+                                              _b(keep), _d(d), _d(stat)), "pcr_reject_centroid_dist")
+    else:
+        if isinstance(reduce, Comm):
+            fn, user = C.cast(lib().pcr_reduce17_with_comm, _vp), reduce.h
+        else:
+            def hook(_user, ptr, _f=reduce):
+                try:
+                    return int(_f(ptr) or 0)
+                except Exception:  # an exception cannot cross the C frame: report a failure status instead
+                    import traceback
+                    traceback.print_exc()
+                    return -1
+            cb = REDUCE17_FN(hook)
+            fn, user = C.cast(cb, _vp), None
+        _check(lib().pcr_reject_centroid_dist_sharded(ctx.h, src_index.h, tgt_index.h, _d(pp), _d(pq), P, msn, msd, cdf,
+                                                      _b(keep), _d(d), _d(stat), fn, user),
+               "pcr_reject_centroid_dist_sharded")
     return dict(keep=keep, d=d, mean=stat[0], sigma=stat[1], kept=int(keep.sum()))

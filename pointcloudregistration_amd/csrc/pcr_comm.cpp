@@ -120,6 +120,8 @@ int pcr_allreduce_partials(pcr_comm *comm, double *partials_d) {
     return PCR_OK;
 }
 
+int pcr_reduce17_with_comm(void *comm, double *buf17_d) { return pcr_allreduce_partials((pcr_comm *)comm, buf17_d); }
+
 int pcr_comm_destroy(pcr_comm *comm) {
     if (!comm) return PCR_OK;
     Rccl *R = rccl();

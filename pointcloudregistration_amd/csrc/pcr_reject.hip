@@ -130,9 +130,11 @@ __global__ void __launch_bounds__(256) reject_stat_brute_kernel(MultiView src, M
     d_out[i] = fabs(st - ss);
 }
 
-// out[0] = sum_i f(d_i), f = identity (center == NULL) or (d - *center)^2.  One block, fixed order.
+// out[0] = sum_i f(d_i), f = identity (center == NULL) or (d - *center)^2; out[1] = count_slot ? P : untouched;
+// out[2..16] = 0.  One block, fixed order.  `out` is a 17-double exchange buffer: in a sharded run every rank's is
+// summed (the all-reduce the fit loop uses for its 17 partials) before finish_stat_kernel divides.
 __global__ void __launch_bounds__(1024) sum_kernel(const double *__restrict__ d, uint32_t P,
-                                                   const double *__restrict__ center, double divisor,
+                                                   const double *__restrict__ center, int count_slot,
                                                    double *__restrict__ out) {
     __shared__ double sm[1024];
     const double c = center ? *center : 0.0;
@@ -147,7 +149,18 @@ __global__ void __launch_bounds__(1024) sum_kernel(const double *__restrict__ d,
         if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *out = sm[0] / divisor;
+    if (threadIdx.x == 0) out[0] = sm[0];
+    if (threadIdx.x == 1 && count_slot) out[1] = (double)P;
+    if (threadIdx.x >= 2 && threadIdx.x < 17) out[threadIdx.x] = 0.0;
+}
+
+// stat[which] = x[0] / count: the mean (:34-35), then the population variance (:36-37), over ALL ranks' pairs.
+// total_out (nullable) keeps the pair count for the second call, whose exchange buffer no longer carries it.
+__global__ void finish_stat_kernel(const double *__restrict__ x, const double *__restrict__ count, double *__restrict__ stat,
+                                   int which, double *__restrict__ total_out) {
+    const double n = *count;
+    stat[which] = x[0] / n;
+    if (total_out) *total_out = n;
 }
 
 __global__ void __launch_bounds__(256) reject_mask_kernel(const double *__restrict__ d, uint32_t P,
@@ -163,13 +176,14 @@ __global__ void __launch_bounds__(256) reject_mask_kernel(const double *__restri
 
 using namespace pcr;
 
-extern "C" int pcr_reject_centroid_dist(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const double *pair_p,
-                                        const double *pair_q, uint32_t P, uint32_t msn, double msd, double cdf,
-                                        uint8_t *out_keep, double *out_d, double *out_stat) {
-    PCR_REQUIRE(ctx && src && tgt && out_keep, "pcr_reject_centroid_dist: NULL argument");
+static int reject_impl(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const double *pair_p,
+                       const double *pair_q, uint32_t P, uint32_t msn, double msd, double cdf, uint8_t *out_keep,
+                       double *out_d, double *out_stat, pcr_reduce17_fn reduce, void *reduce_user) {
+    PCR_REQUIRE(ctx && src && tgt && (out_keep || P == 0), "pcr_reject_centroid_dist: NULL argument");
     PCR_REQUIRE(src->ctx->device == ctx->device && tgt->ctx->device == ctx->device, "pcr_reject_centroid_dist: index lives on another device");
     PCR_REQUIRE(src->kind == tgt->kind, "pcr_reject_centroid_dist: indices must be of the same kind");
-    PCR_REQUIRE(P > 0 && pair_p && pair_q, "pcr_reject_centroid_dist: empty pair set (reference asserts, :27)");
+    // (a rank of a sharded run may hold no pair at all: it still takes part in both reductions)
+    PCR_REQUIRE((P > 0 && pair_p && pair_q) || (P == 0 && reduce), "pcr_reject_centroid_dist: empty pair set (reference asserts, :27)");
     PCR_REQUIRE(msn >= 1 && msn <= src->n && msn <= tgt->n, "pcr_reject_centroid_dist: MSN=%u out of range", msn);
     if (msn > PCR_MAX_K) {
         set_last_error("pcr_reject_centroid_dist: MSN=%u above PCR_MAX_K=%u", msn, PCR_MAX_K);
@@ -178,13 +192,14 @@ extern "C" int pcr_reject_centroid_dist(pcr_ctx *ctx, const pcr_index *src, cons
     PCR_HIP(hipSetDevice(ctx->device));
     double *pp_d = nullptr, *pq_d = nullptr, *d_d = nullptr;
     uint8_t *k_d = nullptr;
-    const size_t bytes = sizeof(double) * 3 * (size_t)P;
+    const size_t bytes = sizeof(double) * 3 * (size_t)(P ? P : 1);
+    int reduce_rc = PCR_OK;
     hipError_t e = hipMalloc(&pp_d, bytes);
     if (e == hipSuccess) e = hipMalloc(&pq_d, bytes);
-    if (e == hipSuccess) e = hipMalloc(&d_d, sizeof(double) * P);
-    if (e == hipSuccess) e = hipMalloc(&k_d, P);
-    if (e == hipSuccess) e = hipMemcpyAsync(pp_d, pair_p, bytes, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(pq_d, pair_q, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMalloc(&d_d, sizeof(double) * (P ? P : 1));
+    if (e == hipSuccess) e = hipMalloc(&k_d, P ? P : 1);
+    if (e == hipSuccess && P) e = hipMemcpyAsync(pp_d, pair_p, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && P) e = hipMemcpyAsync(pq_d, pair_q, bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
         const uint32_t nb = (P + 255) / 256;
         const uint32_t *qorder = nullptr;
@@ -210,7 +225,7 @@ extern "C" int pcr_reject_centroid_dist(pcr_ctx *ctx, const pcr_index *src, cons
             hipLaunchKernelGGL(reject_stat_brute_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, src->view,         \
                                tgt->view, (const double *)pp_d, (const double *)pq_d, P, (int)msn, msd, d_d);       \
     } while (0)
-        {
+        if (P) {
             ProfScope ps(ctx, PCR_PROF_KNN);  // (timed with the K-NN class: two K = MSN searches per pair)
             if (msn <= 4)
                 LAUNCH_STAT(4);
@@ -222,16 +237,24 @@ extern "C" int pcr_reject_centroid_dist(pcr_ctx *ctx, const pcr_index *src, cons
                 LAUNCH_STAT(32);
         }
 #undef LAUNCH_STAT
-        double *stat_d = ctx->result_d + 20;  // [mean, variance]
+        double *stat_d = ctx->result_d + 20;  // [mean, variance, total pair count]
+        double *xbuf_d = ctx->result_d;       // [17] exchange buffer: {sum, count, 0...}
         hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const double *)d_d, P,
-                           (const double *)nullptr, (double)P, stat_d);
+                           (const double *)nullptr, 1, xbuf_d);
+        if (reduce) reduce_rc = reduce(reduce_user, xbuf_d);  // sum over ranks of {sum d, P} (enqueued on the stream)
+        hipLaunchKernelGGL(finish_stat_kernel, dim3(1), dim3(1), 0, ctx->stream, (const double *)xbuf_d,
+                           (const double *)(xbuf_d + 1), stat_d, 0, stat_d + 2);
         hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const double *)d_d, P,
-                           (const double *)stat_d, (double)P, stat_d + 1);
-        hipLaunchKernelGGL(reject_mask_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const double *)d_d, P,
-                           (const double *)stat_d, cdf, k_d);
+                           (const double *)stat_d, 0, xbuf_d);
+        if (reduce && reduce_rc == PCR_OK) reduce_rc = reduce(reduce_user, xbuf_d);  // sum over ranks of sum (d - mean)^2
+        hipLaunchKernelGGL(finish_stat_kernel, dim3(1), dim3(1), 0, ctx->stream, (const double *)xbuf_d,
+                           (const double *)(stat_d + 2), stat_d, 1, (double *)nullptr);
+        if (P)
+            hipLaunchKernelGGL(reject_mask_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const double *)d_d, P,
+                               (const double *)stat_d, cdf, k_d);
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(out_keep, k_d, P, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess && out_d) e = hipMemcpyAsync(out_d, d_d, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && P) e = hipMemcpyAsync(out_keep, k_d, P, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && out_d && P) e = hipMemcpyAsync(out_d, d_d, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess)
             e = hipMemcpyAsync(ctx->result_h + 20, stat_d, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -245,5 +268,23 @@ extern "C" int pcr_reject_centroid_dist(pcr_ctx *ctx, const pcr_index *src, cons
     if (d_d) hipFree(d_d);
     if (k_d) hipFree(k_d);
     PCR_HIP(e);
+    if (reduce_rc != PCR_OK) {
+        set_last_error("pcr_reject_centroid_dist_sharded: the reduction hook failed (%d)", reduce_rc);
+        return reduce_rc < 0 ? reduce_rc : PCR_E_INVALID;
+    }
     return PCR_OK;
+}
+
+extern "C" int pcr_reject_centroid_dist(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const double *pair_p,
+                                        const double *pair_q, uint32_t P, uint32_t msn, double msd, double cdf,
+                                        uint8_t *out_keep, double *out_d, double *out_stat) {
+    return reject_impl(ctx, src, tgt, pair_p, pair_q, P, msn, msd, cdf, out_keep, out_d, out_stat, nullptr, nullptr);
+}
+
+extern "C" int pcr_reject_centroid_dist_sharded(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt,
+                                                const double *pair_p, const double *pair_q, uint32_t P, uint32_t msn,
+                                                double msd, double cdf, uint8_t *out_keep, double *out_d,
+                                                double *out_stat, pcr_reduce17_fn reduce, void *reduce_user) {
+    PCR_REQUIRE(reduce, "pcr_reject_centroid_dist_sharded: NULL reduction hook");
+    return reject_impl(ctx, src, tgt, pair_p, pair_q, P, msn, msd, cdf, out_keep, out_d, out_stat, reduce, reduce_user);
 }

@@ -287,7 +287,8 @@ void CRejectionCentroidDistGPU::_rejectInvalidPairsV(const CorrespondencePairSet
     emptyPairSet(voValid);
     if (!vAll.first.get() || !vAll.second.get()) return;
     const VecColVector3 &AllSrc = vAll.first->getPointSet(), &AllTgt = vAll.second->getPointSet();
-    if (AllSrc.empty() || AllSrc.size() != AllTgt.size()) return;
+    if (AllSrc.size() != AllTgt.size()) return;
+    if (AllSrc.empty() && !m_Reduce) return;  // (a rank of a sharded run without pairs still takes part in the reductions)
     CDeviceSession *pSession = CDeviceSession::getInstance();
     const SDeviceCloud *pSrc = pSession->acquire(m_pSourcePointCloud), *pTgt = pSession->acquire(m_pTargetPointCloud);
     if (!pSrc || !pTgt) {
@@ -305,9 +306,13 @@ void CRejectionCentroidDistGPU::_rejectInvalidPairsV(const CorrespondencePairSet
     flatten(AllSrc, FlatSrc);
     flatten(AllTgt, FlatTgt);
     std::vector<unsigned char> Keep(AllSrc.size());
-    const int Status = pcr_reject_centroid_dist(pSession->context(), pSrc->pIndex, pTgt->pIndex, FlatSrc.data(), FlatTgt.data(),
-                                                (uint32_t)AllSrc.size(), (uint32_t)NumNeighbors, MaxSearchDist, CriticalDistFactor,
-                                                Keep.data(), NULL, NULL);
+    const int Status =
+        m_Reduce ? pcr_reject_centroid_dist_sharded(pSession->context(), pSrc->pIndex, pTgt->pIndex, FlatSrc.data(), FlatTgt.data(),
+                                                    (uint32_t)AllSrc.size(), (uint32_t)NumNeighbors, MaxSearchDist,
+                                                    CriticalDistFactor, Keep.data(), NULL, NULL, m_Reduce, m_ReduceUser)
+                 : pcr_reject_centroid_dist(pSession->context(), pSrc->pIndex, pTgt->pIndex, FlatSrc.data(), FlatTgt.data(),
+                                            (uint32_t)AllSrc.size(), (uint32_t)NumNeighbors, MaxSearchDist, CriticalDistFactor,
+                                            Keep.data(), NULL, NULL);
     if (Status != PCR_OK) {
         warn(__EXCEPTION_SITE__, "pcr_reject_centroid_dist", Status);
         return;

@@ -151,9 +151,16 @@ public:
     static std::string getKeyMaxSearchNum() { return toUpperCopy("RejectionCentroidDist.MSN"); }
     static std::string getKeyMaxSearchDist() { return toUpperCopy("RejectionCentroidDist.MSD"); }
     static std::string getKeyCriticalDistFactor() { return toUpperCopy("RejectionCentroidDist.CDF"); }
+    // Pairs sharded over ranks (no reference counterpart): mean and sigma are then taken over ALL ranks' pairs, summed
+    // through this hook (pcr_reject_centroid_dist_sharded); NULL (the default): every pair is here.
+    void setReduction(pcr_reduce17_fn vReduce, void *vUser) { m_Reduce = vReduce; m_ReduceUser = vUser; }
 
 protected:
     virtual void _rejectInvalidPairsV(const CorrespondencePairSet &vAllCorrespondencePairs, CorrespondencePairSet &voValidCorrespondencePairs);
+
+private:
+    pcr_reduce17_fn m_Reduce = NULL;
+    void *m_ReduceUser = NULL;
 };
 
 class CTransformationEstimationSVD2GPU : public CBaseTransformationEstimation {

@@ -169,3 +169,71 @@ def test_centroid_rejection_nested_equals_flat_equals_oracle(pcr, ctx, oracle, s
         want = oracle.reject_centroid_dist(src, tgt, pp, pq, msn=25, msd=msd, cdf=1.0)
         np.testing.assert_allclose(a["d"], want["d"], rtol=1e-12, atol=1e-15)
         assert (a["keep"] == want["keep"]).mean() > 0.9999   # a pair exactly on the tolerance may flip with the sum order
+
+
+def test_sharded_centroid_rejection_equals_whole(pcr, oracle):
+    """pcr_reject_centroid_dist_sharded (the second exchange): the pairs split over two "ranks" -- two
+    threads, a context each, sharing the indices; the reduction hook sums the 17-double exchange buffers of both through
+    the host -- must give every pair the statistic and the verdict the single call over all pairs gives; an empty
+    shard and a one-rank communicator change nothing at all."""
+    import ctypes as C
+    import threading
+    from pointcloudregistration_amd import synth
+    src, tgt, Rt, tt = synth.registration_pair(30000, 30000, 99)
+    R, T = synth.coarse_initial_transform(Rt, tt, 30000)
+    ctxs = [pcr.Context(0), pcr.Context(0)]
+    six, tix = pcr.Index(ctxs[0], pcr.Cloud(ctxs[0], src)), pcr.Index(ctxs[0], pcr.Cloud(ctxs[0], tgt))
+    U = tix.unique_sq_dist()
+    st = pcr.icp_step(ctxs[0], six, tix, R, T, 4, U * 36.0, U * 4.0, exact=True)
+    kp = st["keep"].astype(bool)
+    pp, pq = oracle.transform(src, R, T)[kp], tgt[st["fwd"][kp]]
+    assert len(pp) > 5000
+    whole = pcr.reject_centroid_dist(ctxs[0], six, tix, pp, pq, msn=25, msd=8.0, cdf=1.0)
+    want = oracle.reject_centroid_dist(src, tgt, pp, pq, msn=25, msd=8.0, cdf=1.0)
+    assert (whole["keep"] == want["keep"]).all() and 0 < whole["kept"] < len(pp)
+
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def run(shards):
+        gate = threading.Barrier(len(shards))
+        slots = [np.zeros(17) for _ in shards]
+        calls = [0] * len(shards)
+        out = [None] * len(shards)
+
+        def rank(r):
+            def reduce(ptr):
+                ctxs[r].synchronize()
+                assert hip.hipMemcpy(slots[r].ctypes.data, ptr, 17 * 8, 2) == 0   # device -> host
+                gate.wait()
+                total = sum(slots)               # the same order on every rank
+                gate.wait()                      # (nobody overwrites a slot that another rank still reads)
+                assert hip.hipMemcpy(ptr, total.ctypes.data, 17 * 8, 1) == 0      # host -> device
+                calls[r] += 1
+            lo, hi = shards[r]
+            out[r] = pcr.reject_centroid_dist(ctxs[r], six, tix, pp[lo:hi], pq[lo:hi], msn=25, msd=8.0, cdf=1.0, reduce=reduce)
+        th = [threading.Thread(target=rank, args=(r,)) for r in range(len(shards))]
+        [t.start() for t in th]
+        [t.join(120) for t in th]
+        assert calls == [2] * len(shards)
+        return out
+
+    h = len(pp) // 2 + 17
+    a, b = run([(0, h), (h, len(pp))])
+    assert (np.concatenate([a["d"], b["d"]]) == whole["d"]).all()
+    for o in (a, b):   # every rank holds the statistics of ALL pairs (sums associate differently: last bits)
+        assert abs(o["mean"] - whole["mean"]) <= 1e-12 * whole["mean"] and abs(o["sigma"] - whole["sigma"]) <= 1e-12 * whole["sigma"]
+    assert (np.concatenate([a["keep"], b["keep"]]) == whole["keep"]).all()
+    a, b = run([(0, len(pp)), (0, 0)])   # a rank without pairs still takes part in both reductions
+    assert (a["keep"] == whole["keep"]).all() and a["mean"] == whole["mean"] and a["sigma"] == whole["sigma"]
+    assert b["kept"] == 0 and b["mean"] == whole["mean"]
+    try:
+        comm = pcr.Comm(ctxs[0], 0, 1, pcr.Comm.unique_id())
+    except pcr.PcrError:
+        comm = None   # RCCL not loadable on this box: the hook path above has covered the logic
+    if comm is not None:
+        one = pcr.reject_centroid_dist(ctxs[0], six, tix, pp, pq, msn=25, msd=8.0, cdf=1.0, reduce=comm)
+        assert (one["keep"] == whole["keep"]).all() and one["mean"] == whole["mean"] and one["sigma"] == whole["sigma"]
+        comm.close()
+    for c in ctxs:
+        c.close()
