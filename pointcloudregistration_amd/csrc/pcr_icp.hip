@@ -138,27 +138,43 @@ __device__ __forceinline__ double ld_agent(const double *p) {
 }
 
 // 17 per-lane values -> one value per block and column, stored column-major [17][nblocks] so that the fold
-// reads coalesced.  Wave reduction by shuffles, then LDS across the 4 waves.
-__device__ __forceinline__ void block_reduce17(double (&v)[17], double *__restrict__ out, uint32_t block,
-                                               uint32_t nblocks) {
-    __shared__ double sm[4][17];
-#pragma unroll
-    for (int j = 0; j < 17; ++j) {
-        double x = v[j];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-        v[j] = x;
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j < 17; ++j) sm[wave][j] = v[j];
-    }
+// reads coalesced.  Through LDS, not shuffles: every lane parks its 17 values (17 conflict-free writes), then 16 lanes
+// per column add 16 values each and a 4-step shuffle tree finishes the column -- about 65 instructions per wave where
+// a 6-step shuffle tree per value costs over 300 (8 % of the filtered step kernel).  Fixed order: reproducible bit for
+// bit, and the same in every kernel that ends this way.
+//   lds: REDUCE17_LDS_BYTES of shared memory that the block no longer needs for anything else (the kernels hand over
+//   the buffer their search used: the barrier at the top waits for every wave to be done with it).
+constexpr int REDUCE17_STRIDE = 256 + 16;  // doubles per column: columns 16 lanes apart land on different banks
+constexpr int REDUCE17_LDS_BYTES = 17 * REDUCE17_STRIDE * 8;
+__device__ __forceinline__ void block_reduce17(double (&v)[17], double *__restrict__ lds, double *__restrict__ out,
+                                               uint32_t block, uint32_t nblocks) {
+    const uint32_t tid = threadIdx.x;
     __syncthreads();
-    // a device-scope (write-through) store: the in-kernel fold of another block, on another XCD, reads it
-    if (threadIdx.x < 17)
-        st_agent(&out[(size_t)threadIdx.x * nblocks + block],
-                 (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]));
+#pragma unroll
+    for (int j = 0; j < 17; ++j) lds[j * REDUCE17_STRIDE + tid] = v[j];
+    __syncthreads();
+    const uint32_t col = tid >> 4, part = tid & 15u;
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += lds[col * REDUCE17_STRIDE + i * 16 + part];
+    s += __shfl_xor(s, 8, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 1, 64);
+    // device-scope (write-through) stores: the in-kernel fold of another block, on another XCD, reads them
+    if (part == 0u) st_agent(&out[(size_t)col * nblocks + block], s);
+    if (tid < 64u) {  // the seventeenth column: the first wave once more (16 of its lanes hold real data)
+        double s16 = 0.0;
+        if (tid < 16u) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s16 += lds[16 * REDUCE17_STRIDE + i * 16 + tid];
+        }
+        s16 += __shfl_xor(s16, 8, 64);
+        s16 += __shfl_xor(s16, 4, 64);
+        s16 += __shfl_xor(s16, 2, 64);
+        s16 += __shfl_xor(s16, 1, 64);
+        if (tid == 0u) st_agent(&out[(size_t)16 * nblocks + block], s16);
+    }
 }
 
 template <class DY>
@@ -280,8 +296,10 @@ __global__ void __launch_bounds__(256, MULTI ? PCR_MULTI_WAVES : PCR_STEP_WAVES)
     const bool fin = live && isfinite(px) && isfinite(py) && isfinite(pz);
     TopK<KC> top;
     top.init(fmax_d2);
-    __shared__ uint2 rowtab[9][256];  // per-lane row table of the ring walk (knn_device.h)
-    uint2 *my_rows = &rowtab[0][threadIdx.x];
+    // per-lane row table of the ring walk (knn_device.h: rows 256 slots apart), later the block reduction's scratch
+    __shared__ __align__(16) unsigned char smem[REDUCE17_LDS_BYTES];
+    static_assert(sizeof(uint2) * 9 * 256 <= REDUCE17_LDS_BYTES, "row table fits");
+    uint2 *my_rows = (uint2 *)smem + threadIdx.x;
     if constexpr (MULTI) {  // (every lane calls: the level search finishes its longest queries wave-cooperatively)
         multi_lane_search<KC>(A.tgt, A.tgt_mem, A.tgt.all, fin, px, py, pz, px, py, pz, fmax_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
                               my_rows);
@@ -334,7 +352,7 @@ __global__ void __launch_bounds__(256, MULTI ? PCR_MULTI_WAVES : PCR_STEP_WAVES)
         if (A.out_rev) A.out_rev[slot] = r;
         if (A.out_keep) A.out_keep[slot] = keep ? 1 : 0;
     }
-    block_reduce17(acc, A.block_partials, lb, gridDim.x);
+    block_reduce17(acc, (double *)smem, A.block_partials, lb, gridDim.x);
 #ifdef PCR_BLOCK_TIMES
     if (threadIdx.x == 0 && lb < 65536u) g_block_times[2 * lb + 1] = wall_clock64();
 #endif
@@ -352,8 +370,8 @@ template <int KC>
 __device__ __forceinline__ void fast_step_body(const StepArgs *__restrict__ Ap, uint32_t lb, uint32_t nb) {
     if (Ap->dyn->done) return;  // uniform over the problem's blocks
     const uint32_t t = lb * 256u + threadIdx.x;
-    __shared__ uint2 rowtab[9][256];
-    uint2 *my_rows = &rowtab[0][threadIdx.x];
+    __shared__ __align__(16) unsigned char smem[REDUCE17_LDS_BYTES];  // row tables, then the block reduction's scratch
+    uint2 *my_rows = (uint2 *)smem + threadIdx.x;
     uint32_t pos = 0, orig = 0, slot = 0;
     double px = 0, py = 0, pz = 0;
     bool live;
@@ -472,7 +490,7 @@ __device__ __forceinline__ void fast_step_body(const StepArgs *__restrict__ Ap, 
         if (A->out_rev) A->out_rev[slot] = r;
         if (A->out_keep) A->out_keep[slot] = keep ? 1 : 0;
     }
-    block_reduce17(acc, A->block_partials, lb, nb);
+    block_reduce17(acc, (double *)smem, A->block_partials, lb, nb);
     fold_in_kernel(A, lb, nb);
 }
 
@@ -506,7 +524,9 @@ __global__ void __launch_bounds__(256) icp_step_brute_kernel(StepArgs A) {
     const StepDyn *__restrict__ dynp = A.dyn;
     if (dynp->done) return;
     const StepDyn D = *dynp;
-    __shared__ Pt4 tile[512];
+    __shared__ __align__(32) unsigned char smem[REDUCE17_LDS_BYTES];  // candidate tiles, then the block reduction's scratch
+    static_assert(sizeof(Pt4) * 512 <= REDUCE17_LDS_BYTES, "tile fits");
+    Pt4 *tile = (Pt4 *)smem;
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const bool live = t < A.m;
     double acc[17];
@@ -578,7 +598,7 @@ __global__ void __launch_bounds__(256) icp_step_brute_kernel(StepArgs A) {
         if (A.out_rev) A.out_rev[slot] = r;
         if (A.out_keep) A.out_keep[slot] = keep ? 1 : 0;
     }
-    block_reduce17(acc, A.block_partials, blockIdx.x, gridDim.x);
+    block_reduce17(acc, (double *)smem, A.block_partials, blockIdx.x, gridDim.x);
     fold_in_kernel(&A, blockIdx.x, gridDim.x);
 }
 
@@ -613,7 +633,8 @@ __global__ void __launch_bounds__(256) reduce_pairs_kernel(const double *__restr
         const double qx = pq[3 * (size_t)t], qy = pq[3 * (size_t)t + 1], qz = pq[3 * (size_t)t + 2];
         accumulate(acc, true, px, py, pz, qx, qy, qz, sqdist3(px, py, pz, qx, qy, qz), D);
     }
-    block_reduce17(acc, block_partials, blockIdx.x, gridDim.x);
+    __shared__ __align__(16) unsigned char smem[REDUCE17_LDS_BYTES];
+    block_reduce17(acc, (double *)smem, block_partials, blockIdx.x, gridDim.x);
 }
 
 static double clouds_scale(const pcr_cloud *a, const pcr_cloud *b) {
@@ -652,17 +673,21 @@ __global__ void fit_init_kernel(FitDev value, FitDev *dst) { *dst = value; }
 
 // One thread: what CIterativeFit::_fitStepV does after the correspondences (IterativeFit.cpp:156-174) --
 // computeRotationAndTranslation, then the convergence criteria -- followed by the preparation of the next step.
-__device__ __noinline__ void fit_solve_body(FitDev *F, const double *partials, double *traj) {
+__device__ __noinline__ void fit_solve_body(FitDev *__restrict__ F, const double *__restrict__ partials,
+                                            double *__restrict__ traj) {
     if (F->dyn.done) return;
     double part[17];
     for (int i = 0; i < 17; ++i) part[i] = partials[i];
-    const uint32_t it = F->iteration + 1;  // the reference counts from 1 (IterativeFit.cpp:121-123)
+    // one thread, and every load from device memory costs it a microsecond: fetch the whole state at once (all loads in
+    // flight together) and read the copy from here on; stores go to *F
+    const FitDev f = *F;
+    const uint32_t it = f.iteration + 1;  // the reference counts from 1 (IterativeFit.cpp:121-123)
     F->iteration = it;
     F->last_n = part[0];
     double R[9], T[3];
-    for (int i = 0; i < 9; ++i) R[i] = F->dyn.M.r[i];
-    for (int i = 0; i < 3; ++i) T[i] = F->dyn.M.t[i];
-    double *row = (traj && it <= F->traj_cap) ? traj + (size_t)(it - 1) * 14 : nullptr;
+    for (int i = 0; i < 9; ++i) R[i] = f.dyn.M.r[i];
+    for (int i = 0; i < 3; ++i) T[i] = f.dyn.M.t[i];
+    double *row = (traj && it <= f.traj_cap) ? traj + (size_t)(it - 1) * 14 : nullptr;
     if (!(part[0] >= 1.0)) {  // the reference divides by zero here (RegUtilityFunctions.cpp:71)
         F->state = PCR_FIT_NO_CORRESPONDENCES;
         F->dyn.done = 1;
@@ -675,7 +700,7 @@ __device__ __noinline__ void fit_solve_body(FitDev *F, const double *partials, d
         return;
     }
     double mse;
-    solve_rigid_core(part, F->dyn.pivot_p, F->dyn.pivot_q, R, T, nullptr, nullptr, &mse);
+    solve_rigid_core(part, f.dyn.pivot_p, f.dyn.pivot_q, R, T, nullptr, nullptr, &mse);
     F->last_mse = mse;
     if (row) {
         for (int i = 0; i < 9; ++i) row[i] = R[i];
@@ -686,9 +711,10 @@ __device__ __noinline__ void fit_solve_body(FitDev *F, const double *partials, d
     // ---- CDefaultConvergenceCriteria::_isConvergedV (DefaultConvergenceCriterial.cpp:69-83): short-circuit OR
     int state = PCR_FIT_NOT_CONVERGED;
     bool converged = false;
-    if (F->conv_enabled) {
-        const pcr_convergence_params &c = F->conv;
-        uint32_t similar = F->similar;
+    double cur_mse = f.cur_mse;  // (stays as it was when an earlier test of the short-circuit chain fires)
+    if (f.conv_enabled) {
+        const pcr_convergence_params &c = f.conv;
+        uint32_t similar = f.similar;
         auto gate = [&](int st) {  // the MIST counter shared by the three tests (:111-123)
             if (similar < c.max_similar) {
                 ++similar;
@@ -707,24 +733,25 @@ __device__ __noinline__ void fit_solve_body(FitDev *F, const double *partials, d
                 }
             }
             double rot = 0;  // (:103-133); T is the ACCUMULATED translation
-            for (int i = 0; i < 9; ++i) rot += (F->pre_rot[i] - R[i]) * (F->pre_rot[i] - R[i]);
+            for (int i = 0; i < 9; ++i) rot += (f.pre_rot[i] - R[i]) * (f.pre_rot[i] - R[i]);
             const double tr = T[0] * T[0] + T[1] * T[1] + T[2] * T[2];
             if (rot < c.rotation_threshold && tr < c.translation_threshold && gate(PCR_FIT_TRANSFORM)) {
                 converged = true;
                 break;
             }
-            F->cur_mse = mse;  // (:137-170)
-            if (fabs(F->cur_mse - F->pre_mse) < c.abs_mse * F->uniq && gate(PCR_FIT_ABS_MSE)) {
+            cur_mse = mse;  // (:137-170)
+            if (fabs(cur_mse - f.pre_mse) < c.abs_mse * f.uniq && gate(PCR_FIT_ABS_MSE)) {
                 converged = true;
                 break;
             }
-            if (fabs(F->cur_mse - F->pre_mse) / F->pre_mse < c.rel_mse * F->uniq && gate(PCR_FIT_REL_MSE)) {  // (:174-207)
+            if (fabs(cur_mse - f.pre_mse) / f.pre_mse < c.rel_mse * f.uniq && gate(PCR_FIT_REL_MSE)) {  // (:174-207)
                 converged = true;
                 break;
             }
         } while (false);
         F->similar = similar;
-        F->pre_mse = F->cur_mse;  // (:77-79)
+        F->cur_mse = cur_mse;
+        F->pre_mse = cur_mse;  // (:77-79)
         for (int i = 0; i < 9; ++i) F->pre_rot[i] = R[i];
     } else {
         F->cur_mse = mse;
@@ -732,7 +759,7 @@ __device__ __noinline__ void fit_solve_body(FitDev *F, const double *partials, d
     F->state = state;
     // ---- next iteration's constants
     StepDyn next;
-    const bool ok = make_dyn(R, T, F->c_src, F->c_tgt, F->cloud_scale, next, nullptr);
+    const bool ok = make_dyn(R, T, f.c_src, f.c_tgt, f.cloud_scale, next, nullptr);
     if (!ok) {
         F->state = PCR_FIT_DEGENERATE;
         converged = true;
@@ -741,13 +768,13 @@ __device__ __noinline__ void fit_solve_body(FitDev *F, const double *partials, d
     {
         // |p_new - p_old| = |dR (s - c) + (dR c + dT)| <= |dR|_F * rad + |dR c + dT| for every source point s
         double fro = 0, v[3];
-        for (int i = 0; i < 9; ++i) fro += (R[i] - F->dyn.M.r[i]) * (R[i] - F->dyn.M.r[i]);
+        for (int i = 0; i < 9; ++i) fro += (R[i] - f.dyn.M.r[i]) * (R[i] - f.dyn.M.r[i]);
         for (int r = 0; r < 3; ++r)
-            v[r] = (R[r] - F->dyn.M.r[r]) * F->c_src[0] + (R[3 + r] - F->dyn.M.r[3 + r]) * F->c_src[1] +
-                   (R[6 + r] - F->dyn.M.r[6 + r]) * F->c_src[2] + (T[r] - F->dyn.M.t[r]);
-        const double disp = sqrt(fro) * F->src_rad + sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+            v[r] = (R[r] - f.dyn.M.r[r]) * f.c_src[0] + (R[3 + r] - f.dyn.M.r[3 + r]) * f.c_src[1] +
+                   (R[6 + r] - f.dyn.M.r[6 + r]) * f.c_src[2] + (T[r] - f.dyn.M.t[r]);
+        const double disp = sqrt(fro) * f.src_rad + sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
         // slack: the roundings of both evaluations of R*s + T, and of this bound itself
-        next.disp_bound = __double2float_ru(disp * 1.000001 + 1e-12 * (F->cloud_scale + fabs(T[0]) + fabs(T[1]) + fabs(T[2])));
+        next.disp_bound = __double2float_ru(disp * 1.000001 + 1e-12 * (f.cloud_scale + fabs(T[0]) + fabs(T[1]) + fabs(T[2])));
     }
     F->dyn = next;
 }
