@@ -202,6 +202,23 @@ int pcr_icp_step(pcr_ctx *ctx, const pcr_index *src_index, const pcr_index *tgt_
                  const uint32_t *sample_idx /*nullable*/, uint32_t m, const double R[9], const double T[3],
                  uint32_t k, double thr_fwd_sq, double thr_rev_sq, uint32_t flags, double partials[17],
                  uint32_t *out_fwd, uint32_t *out_rev, uint8_t *out_keep);
+/* ---- f4, OPT-IN: the normal-aware pair decision CCorrespondenceEstimationClosestPoints::__insertFitPairs
+ *      (CorrespondenceEstimationClosestPoints.cpp:128-175; its call is commented out in the reference, :105) ----
+ * In place of the reciprocal gate: the K forward neighbours of p = R*s + T are tried nearest first, and the first one
+ * whose direction from p is (anti)parallel to its own normal to within nvdt -- |1 - |cos|| < NVDT (0.0125) -- makes the
+ * pair; with compare_normals != 0 its normal must also agree with the sample's rotated normal, |n . R n_s| > ndt (0.85;
+ * the reference hard-wires that test off).  Normals are attached to the clouds with pcr_cloud_set_normals (host
+ * double[3n], original order; copied) or pcr_cloud_set_normals_d (borrowed device pointer); NULL detaches.
+ * NOT the reference's observable behaviour: there the function reads a vector it never assigns (TmpTgtPoint, :139,
+ * :146, :166) -- here that vector is the neighbour's position.  Grid indices only.  partials/out_keep as in
+ * pcr_icp_step; out_tgt (nullable) = the chosen target index or PCR_NO_INDEX, laid out like out_fwd. */
+int pcr_cloud_set_normals(pcr_cloud *cloud, const double *normals /*nullable*/);
+int pcr_cloud_set_normals_d(pcr_cloud *cloud, const double *normals_d /*nullable*/);
+int pcr_icp_step_normal_fit(pcr_ctx *ctx, const pcr_index *src_index, const pcr_index *tgt_index,
+                            const uint32_t *sample_idx /*nullable*/, uint32_t m, const double R[9], const double T[3],
+                            uint32_t k, double nvdt, double ndt, int compare_normals, double partials[17],
+                            uint32_t *out_tgt, uint8_t *out_keep);
+
 /* device-resident variant for the multi-GPU loop: sample_idx_d [m] (nullable) on the device,
  * partials_d [17] on the device (ready for an RCCL all-reduce on the same stream).  With sample_idx_d NULL the
  * output arrays need n entries (see above), whatever m is. */

@@ -178,6 +178,84 @@ uint32_t orc_icrp_correspondences(const double *src, uint32_t ns, const double *
     return P;
 }
 
+// Eigen's Vector3d::normalize() of the reference's vintage: *this /= sqrt(squaredNorm()), no zero test (a zero
+// vector becomes NaN); squaredNorm and dot sum left to right.
+static inline void normalize3(double v[3]) {
+    const double n = std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    v[0] /= n;
+    v[1] /= n;
+    v[2] /= n;
+}
+
+// ---- f4: CCorrespondenceEstimationClosestPoints::__insertFitPairs (:128-175) as the pair decision of the loop at
+// :84-106, in place of the reciprocal gate (:94-104) -- its call is commented out at :105.  For every sample the K
+// forward neighbours are tried nearest first (:140); the first one whose direction from the sample is (anti)parallel to
+// its own normal to within NVDT (:145-155) -- and, if normals are compared, whose normal agrees with the sample's
+// rotated normal to within NDT (:157-164; the reference hard-wires NoNormalCompare = 1, :133) -- makes the pair (:166-171).
+// ONE unavoidable departure, and the reason this variant is opt-in and "parity unpinned" by construction: the reference
+// reads TmpTgtPoint (:146, :166) without ever assigning it -- line 142 streams the neighbour's POSITION into
+// TmpTgtNormal, which line 143 then overwrites with the normal -- i.e. it computes with an uninitialised vector.  Here
+// TmpTgtPoint is the neighbour's position, which is what line 142 evidently meant to write.
+// vSrcCorNormal is normalised IN PLACE every time a candidate passes the NVDT test (:157), as there.
+uint32_t orc_icrp_normal_fit(const double *src, const double *src_normals, uint32_t ns, const double *tgt,
+                             const double *tgt_normals, uint32_t nt, const void *tgt_tree, const uint32_t *sample_idx,
+                             uint32_t m, const double R[9], const double T[3], uint32_t k, double nvdt, double ndt,
+                             int compare_normals, uint32_t *out_tgt, uint8_t *keep, double *pair_p, double *pair_q,
+                             int threads) {
+    (void)ns;
+    (void)nt;
+    if (orc_kd_old_k(tgt_tree) != k || !tgt_normals || (compare_normals && !src_normals)) return 0;
+    std::vector<uint32_t> chosen(m, ORC_NO_INDEX);
+    const int nth = threads > 1 ? threads : 1;
+#pragma omp parallel for schedule(dynamic, 2048) num_threads(nth)
+    for (long i = 0; i < (long)m; ++i) {
+        const uint32_t si = sample_idx ? sample_idx[i] : (uint32_t)i;
+        double p[3], sn[3] = {0, 0, 0};
+        xform(R, T, src + (size_t)si * 3, p);  // :86
+        if (src_normals) {                      // :87  CurSrcNormal = R * n
+            const double *n = src_normals + (size_t)si * 3;
+            for (int r = 0; r < 3; ++r) sn[r] = (R[r] * n[0] + R[3 + r] * n[1]) + R[6 + r] * n[2];
+        }
+        std::vector<uint32_t> nb(k);
+        orc_kd_old_query_one(tgt_tree, p, nb.data(), nullptr);  // :89, ascending
+        for (uint32_t c = 0; c < k; ++c) {                      // :140
+            const uint32_t j = nb[c];
+            double tn[3] = {tgt_normals[(size_t)j * 3], tgt_normals[(size_t)j * 3 + 1], tgt_normals[(size_t)j * 3 + 2]};  // :143
+            normalize3(tn);                                                                                              // :145
+            const double *q = tgt + (size_t)j * 3;  // TmpTgtPoint: see above
+            double v[3] = {q[0] - p[0], q[1] - p[1], q[2] - p[2]};  // :146
+            normalize3(v);                                          // :147
+            const double nvd = std::fabs(((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) -
+                                         std::fabs((v[0] * tn[0] + v[1] * tn[1]) + v[2] * tn[2]));  // :149
+            if (nvd < nvdt) {                                                                       // :155
+                double nd = 0;
+                if (src_normals) {
+                    normalize3(sn);                                                    // :157
+                    nd = std::fabs((tn[0] * sn[0] + tn[1] * sn[1]) + tn[2] * sn[2]);  // :158
+                }
+                if (!compare_normals || nd > ndt) {  // :164
+                    chosen[i] = j;
+                    break;  // :171
+                }
+            }
+        }
+    }
+    uint32_t P = 0;
+    for (uint32_t i = 0; i < m; ++i) {
+        if (out_tgt) out_tgt[i] = chosen[i];
+        if (keep) keep[i] = chosen[i] != ORC_NO_INDEX;
+        if (chosen[i] != ORC_NO_INDEX) {
+            if (pair_p) {
+                const uint32_t si = sample_idx ? sample_idx[i] : i;
+                xform(R, T, src + (size_t)si * 3, pair_p + (size_t)P * 3);
+            }
+            if (pair_q) std::memcpy(pair_q + (size_t)P * 3, tgt + (size_t)chosen[i] * 3, 24);
+            ++P;
+        }
+    }
+    return P;
+}
+
 void orc_svd3(const double H[9], double U[9], double S[3], double V[9]) {
     // Two-sided Jacobi (the method published for Eigen::JacobiSVD on real square input):
     // sweep the (p,q) pairs; each 2x2 block is first made symmetric by a left rotation, then

@@ -236,6 +236,29 @@ class Convergence:
             self.h = None
 
 
+def icrp_normal_fit(src, src_normals, tgt, tgt_normals, tree, R, T, k, nvdt=0.0125, ndt=0.85, compare_normals=False,
+                    sample_idx=None, threads=1):
+    """f4 (opt-in): __insertFitPairs as the pair decision; see icrp.cpp."""
+    src, tgt, tn = _f64(src), _f64(tgt), _f64(tgt_normals)
+    sn = _f64(src_normals) if src_normals is not None else None
+    R, T = np.ascontiguousarray(R, np.float64).reshape(9), np.ascontiguousarray(T, np.float64).reshape(3)
+    if sample_idx is not None:
+        sample_idx = np.ascontiguousarray(sample_idx, np.uint32)
+        m = len(sample_idx)
+    else:
+        m = len(src)
+    out = np.empty(m, np.uint32)
+    keep = np.empty(m, np.uint8)
+    pp, pq = np.empty((m, 3)), np.empty((m, 3))
+    fn = lib().orc_icrp_normal_fit
+    fn.restype = C.c_uint32
+    fn.argtypes = [_dp, _dp, C.c_uint32, _dp, _dp, C.c_uint32, C.c_void_p, _up, C.c_uint32, _dp, _dp, C.c_uint32,
+                   C.c_double, C.c_double, C.c_int, _up, _bp, _dp, _dp, C.c_int]
+    P = fn(_d(src), _d(sn), len(src), _d(tgt), _d(tn), len(tgt), tree.h, _u(sample_idx), m, _d(R), _d(T), k, nvdt, ndt,
+           1 if compare_normals else 0, _u(out), _b(keep), _d(pp), _d(pq), threads)
+    return dict(tgt=out, keep=keep, P=P, pair_p=pp[:P], pair_q=pq[:P])
+
+
 def fit(src, tgt, k=4, sdft=36.0, ndft=4.0, conv=None, R0=None, T0=None, sample_idx=None, threads=1, traj_cap=1024):
     src, tgt = _f64(src), _f64(tgt)
     prm = FitParams(k, sdft, ndft, conv or ConvParams.regcfg())

@@ -63,6 +63,15 @@ uint32_t orc_icrp_correspondences(const double *src, uint32_t ns, const double *
                                   uint32_t *rev, uint8_t *keep, double *pair_p, double *pair_q,
                                   int threads);
 
+/* f4, opt-in: __insertFitPairs (CorrespondenceEstimationClosestPoints.cpp:128-175) as the pair decision, with
+ * TmpTgtPoint := the neighbour's position (the reference reads it unassigned: undefined behaviour there).
+ * out_tgt[m]: the chosen target index or ORC_NO_INDEX.  Returns the number of pairs. */
+uint32_t orc_icrp_normal_fit(const double *src, const double *src_normals, uint32_t ns, const double *tgt,
+                             const double *tgt_normals, uint32_t nt, const void *tgt_tree,
+                             const uint32_t *sample_idx, uint32_t m, const double R[9], const double T[3],
+                             uint32_t k, double nvdt, double ndt, int compare_normals, uint32_t *out_tgt,
+                             uint8_t *keep, double *pair_p, double *pair_q, int threads);
+
 /* ---- CTransformationEstimationSVD2, TransformationEstimationSVD2.cpp:17-117 +
  *      compute3DCentroid (RegUtilityFunctions.cpp:44-72, single slot = Release build) +
  *      accumulateTransformation (BaseTransformationEstimation.h:28-32).

@@ -102,6 +102,10 @@ SYMBOLS = {
     "pcr_reject_centroid_dist_sharded": (C.c_int, [_vp, _vp, _vp, _dp, _dp, C.c_uint32, C.c_uint32, C.c_double,
                                                    C.c_double, _bp, _dp, _dp, _vp, _vp]),
     "pcr_reduce17_with_comm": (C.c_int, [_vp, _vp]),
+    "pcr_cloud_set_normals": (C.c_int, [_vp, _dp]),
+    "pcr_cloud_set_normals_d": (C.c_int, [_vp, _vp]),
+    "pcr_icp_step_normal_fit": (C.c_int, [_vp, _vp, _vp, _up, C.c_uint32, _dp, _dp, C.c_uint32, C.c_double, C.c_double,
+                                          C.c_int, _dp, _up, _bp]),
 }
 REDUCE17_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)  # pcr_reduce17_fn(user, buf17_d)
 
@@ -212,6 +216,12 @@ class Cloud:
             self.n = len(a)
             _check(lib().pcr_cloud_upload(ctx.h, _d(a), self.n, C.byref(self.h)), "pcr_cloud_upload")
 
+    def set_normals(self, normals):
+        """Attach per-point normals (numpy (n,3), copied; None detaches): what icp_step_normal_fit reads."""
+        a = None if normals is None else _f64(normals)
+        assert a is None or len(a) == self.n
+        _check(lib().pcr_cloud_set_normals(self.h, _d(a)), "pcr_cloud_set_normals")
+
     def bounds(self):
         lo, hi = np.empty(3), np.empty(3)
         _check(lib().pcr_cloud_bounds(self.h, _d(lo), _d(hi)), "pcr_cloud_bounds")
@@ -293,6 +303,23 @@ def icp_step(ctx, src_index, tgt_index, R, T, k, thr_fwd_sq, thr_rev_sq, sample_
                               thr_rev_sq, (STEP_EXACT_INDICES if exact else 0) | flags, _d(partials), _u(fwd), _u(rev),
                               _b(keep)), "pcr_icp_step")
     return dict(partials=partials, fwd=fwd, rev=rev, keep=keep)
+
+
+def icp_step_normal_fit(ctx, src_index, tgt_index, R, T, k, nvdt=0.0125, ndt=0.85, compare_normals=False, sample_idx=None):
+    """f4 (opt-in): pcr_icp_step_normal_fit; the clouds of both indices carry normals (Cloud.set_normals)."""
+    R, T = _rt(R, T)
+    if sample_idx is not None:
+        sample_idx = np.ascontiguousarray(sample_idx, np.uint32)
+        m = len(sample_idx)
+    else:
+        m = src_index.n
+    partials = np.empty(17)
+    tgt = np.empty(m, np.uint32)
+    keep = np.empty(m, np.uint8)
+    _check(lib().pcr_icp_step_normal_fit(ctx.h, src_index.h, tgt_index.h, _u(sample_idx), m, _d(R), _d(T), k, nvdt, ndt,
+                                         1 if compare_normals else 0, _d(partials), _u(tgt), _b(keep)),
+           "pcr_icp_step_normal_fit")
+    return dict(partials=partials, tgt=tgt, keep=keep)
 
 
 NOALLOC_MAX_SAMPLES = 4194304

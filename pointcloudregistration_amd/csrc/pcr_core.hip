@@ -853,7 +853,42 @@ int pcr_cloud_free(pcr_cloud *c) {
     if (!c) return PCR_OK;
     hipSetDevice(c->ctx->device);
     if (c->owned && c->xyz_d) hipFree(const_cast<double *>(c->xyz_d));
+    if (c->normals_owned && c->normals_d) hipFree(const_cast<double *>(c->normals_d));
     delete c;
+    return PCR_OK;
+}
+
+static void drop_normals(pcr_cloud *c) {
+    if (c->normals_owned && c->normals_d) hipFree(const_cast<double *>(c->normals_d));
+    c->normals_d = nullptr;
+    c->normals_owned = false;
+}
+
+int pcr_cloud_set_normals(pcr_cloud *c, const double *normals) {
+    PCR_REQUIRE(c, "pcr_cloud_set_normals: NULL cloud");
+    PCR_HIP(hipSetDevice(c->ctx->device));
+    PCR_HIP(hipStreamSynchronize(c->ctx->stream));
+    drop_normals(c);
+    if (!normals || c->n == 0) return PCR_OK;
+    double *d = nullptr;
+    PCR_HIP(hipMalloc(&d, sizeof(double) * 3 * (size_t)c->n));
+    hipError_t e = hipMemcpyAsync(d, normals, sizeof(double) * 3 * (size_t)c->n, hipMemcpyHostToDevice, c->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->ctx->stream);
+    if (e != hipSuccess) {
+        hipFree(d);
+        PCR_HIP(e);
+    }
+    c->normals_d = d;
+    c->normals_owned = true;
+    return PCR_OK;
+}
+
+int pcr_cloud_set_normals_d(pcr_cloud *c, const double *normals_d) {
+    PCR_REQUIRE(c, "pcr_cloud_set_normals_d: NULL cloud");
+    PCR_HIP(hipSetDevice(c->ctx->device));
+    PCR_HIP(hipStreamSynchronize(c->ctx->stream));
+    drop_normals(c);
+    c->normals_d = normals_d;
     return PCR_OK;
 }
 

@@ -97,6 +97,10 @@ struct StepArgs {
     double *fit_traj;
     uint32_t *out_fwd, *out_rev;
     uint8_t *out_keep;
+    // the normal-aware variant only (icp_step_normal_kernel): per-point normals in ORIGINAL order, the two thresholds
+    const double *src_normals, *tgt_normals;
+    double nvdt, ndt;
+    uint32_t compare_normals;
 };
 
 // The filtered kernel reads its arguments from DEVICE memory (a copy of StepArgs), not from the kernel-argument
@@ -356,6 +360,101 @@ __global__ void __launch_bounds__(256, MULTI ? PCR_MULTI_WAVES : PCR_STEP_WAVES)
 #ifdef PCR_BLOCK_TIMES
     if (threadIdx.x == 0 && lb < 65536u) g_block_times[2 * lb + 1] = wall_clock64();
 #endif
+    fold_in_kernel(&A, lb, gridDim.x);
+}
+
+// f4, opt-in (pcr_icp_step_normal_fit): CCorrespondenceEstimationClosestPoints::__insertFitPairs
+// (CorrespondenceEstimationClosestPoints.cpp:128-175) as the pair decision, in place of the reciprocal gate (:94-104);
+// its call is commented out in the reference (:105).  The K forward neighbours are tried nearest first; the first whose
+// direction from the sample is (anti)parallel to its own normal to within NVDT -- and, if asked, whose normal agrees
+// with the sample's rotated normal to within NDT (the reference hard-wires that test off, :133) -- makes the pair.
+// TmpTgtPoint (read unassigned in the reference: :139,:146,:166) is the neighbour's position here; see oracle/icrp.cpp.
+__device__ __forceinline__ void normalize3(double &x, double &y, double &z) {  // Eigen: *this /= sqrt(squaredNorm())
+    const double n = sqrt(dadd(dadd(dmul(x, x), dmul(y, y)), dmul(z, z)));
+    x = x / n;
+    y = y / n;
+    z = z / n;
+}
+template <int KC, bool MULTI>
+__global__ void __launch_bounds__(256, MULTI ? PCR_MULTI_WAVES : PCR_STEP_WAVES) icp_step_normal_kernel(StepArgs A) {
+    const StepDyn *__restrict__ dynp = A.dyn;
+    const StepDyn D = *dynp;
+    const uint32_t lb = MULTI ? xcd_remap_chunked(blockIdx.x, gridDim.x) : xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t t = lb * 256u + threadIdx.x;
+    const bool live = t < A.m;
+    double acc[17];
+#pragma unroll
+    for (int j = 0; j < 17; ++j) acc[j] = 0.0;
+    uint32_t pos = 0, orig = 0, slot = 0;
+    double px = 0, py = 0, pz = 0;
+    if (live) {
+        if (A.sample_idx) {
+            orig = A.sample_idx[t];
+            pos = A.src_pos_of[orig];
+            slot = t;
+        } else {
+            pos = A.src_order[A.sample_begin + t];
+            orig = (uint32_t)A.src.all[pos].w;
+            slot = orig;
+        }
+        const Pt4 s = A.src.all[pos];
+        xform(D.M, s.x, s.y, s.z, px, py, pz);  // (:86)
+    }
+    const bool fin = live && isfinite(px) && isfinite(py) && isfinite(pz);
+    TopK<KC> top;
+    top.init(PCR_INF);
+    __shared__ __align__(16) unsigned char smem[REDUCE17_LDS_BYTES];
+    uint2 *my_rows = (uint2 *)smem + threadIdx.x;
+    if constexpr (MULTI) {
+        multi_lane_search<KC, false, (KC <= 8)>(A.tgt, A.tgt_mem, A.tgt.all, fin, px, py, pz, px, py, pz, PCR_INF,
+                                                1.0 - 1.8189894035458565e-12, 0.0, top, my_rows);
+    } else if (fin) {
+        lane_search<KC>(A.tgt.v[0], A.tgt.all, px, py, pz, px, py, pz, PCR_INF, 1.0 - 1.8189894035458565e-12, 0.0, top, my_rows);
+    }
+    double snx = 0, sny = 0, snz = 0;  // CurSrcNormal = R * n (:87)
+    if (fin && A.src_normals) {
+        const double *n = A.src_normals + (size_t)orig * 3;
+        const double a = n[0], b = n[1], c = n[2];
+        snx = dadd(dadd(dmul(D.M.r[0], a), dmul(D.M.r[3], b)), dmul(D.M.r[6], c));
+        sny = dadd(dadd(dmul(D.M.r[1], a), dmul(D.M.r[4], b)), dmul(D.M.r[7], c));
+        snz = dadd(dadd(dmul(D.M.r[2], a), dmul(D.M.r[5], b)), dmul(D.M.r[8], c));
+    }
+    uint32_t chosen = PCR_NO_INDEX;
+    double qx = 0, qy = 0, qz = 0;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {  // (:140) nearest first
+        const uint32_t j = top.idx[c];
+        if (fin && c < A.k && chosen == PCR_NO_INDEX && j != PCR_NO_INDEX) {
+            const double *nn = A.tgt_normals + (size_t)j * 3;
+            double nx = nn[0], ny = nn[1], nz = nn[2];  // (:143)
+            normalize3(nx, ny, nz);                     // (:145)
+            const Pt4 q = A.tgt.all[A.tgt.pos_of[j]];
+            double vx = q.x - px, vy = q.y - py, vz = q.z - pz;  // (:146)
+            normalize3(vx, vy, vz);                              // (:147)
+            const double nvd = fabs(dadd(dadd(dmul(vx, vx), dmul(vy, vy)), dmul(vz, vz)) -
+                                    fabs(dadd(dadd(dmul(vx, nx), dmul(vy, ny)), dmul(vz, nz))));  // (:149)
+            if (nvd < A.nvdt) {                                                                   // (:155)
+                double nd = 0.0;
+                if (A.src_normals) {
+                    normalize3(snx, sny, snz);                                          // (:157) in place, every time
+                    nd = fabs(dadd(dadd(dmul(nx, snx), dmul(ny, sny)), dmul(nz, snz)));  // (:158)
+                }
+                if (!A.compare_normals || nd > A.ndt) {  // (:164)
+                    chosen = j;
+                    qx = q.x;
+                    qy = q.y;
+                    qz = q.z;
+                }
+            }
+        }
+    }
+    const bool keep = chosen != PCR_NO_INDEX;
+    if (live) {
+        accumulate(acc, keep, px, py, pz, qx, qy, qz, keep ? sqdist3(px, py, pz, qx, qy, qz) : 0.0, D);
+        if (A.out_fwd) A.out_fwd[slot] = chosen;
+        if (A.out_keep) A.out_keep[slot] = keep ? 1 : 0;
+    }
+    block_reduce17(acc, (double *)smem, A.block_partials, lb, gridDim.x);
     fold_in_kernel(&A, lb, gridDim.x);
 }
 
@@ -949,11 +1048,15 @@ static size_t fold_scratch_bytes(uint32_t nb) { return fold_tickets_bytes(nb) + 
 // What pcr_icp_step_d and pcr_icp_step_noalloc_d share: argument checks, the per-iteration constants, the launches.
 // dyn_d and block_partials_d are the step's scratch (device memory beyond inputs and outputs); who owns them is the
 // only difference between the two entry points.
+struct NormalFit {  // the normal-aware variant's thresholds (pcr_icp_step_normal_fit); NULL: the ICRP step
+    double nvdt, ndt;
+    int compare_normals;
+};
 static int step_enqueue(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const uint32_t *sample_idx_d,
                         uint32_t sample_begin, uint32_t m, const double R[9], const double T[3], uint32_t k,
                         double thr_fwd_sq, double thr_rev_sq, uint32_t flags, double *partials_d, uint32_t *out_fwd_d,
                         uint32_t *out_rev_d, uint8_t *out_keep_d, StepScratch *sc_d, double *group_partials_d,
-                        uint32_t *tickets_d, double *block_partials_d, const char *who) {
+                        uint32_t *tickets_d, double *block_partials_d, const char *who, const NormalFit *nf = nullptr) {
     StepArgs A;
     int rc = prepare_step_args(ctx, src, tgt, sample_idx_d, sample_begin, m, k, thr_fwd_sq, thr_rev_sq, flags, A, who);
     if (rc != PCR_OK) return rc;
@@ -980,16 +1083,42 @@ static int step_enqueue(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt
     A.partials_out = partials_d;
     // the per-iteration values and the arguments travel as kernel arguments of tiny kernels: stream-ordered, no staging
     hipLaunchKernelGGL(set_dyn_kernel, dim3(1), dim3(1), 0, ctx->stream, D, &sc_d->dyn);
+    if (nf) {
+        A.src_normals = src->cloud->normals_d;
+        A.tgt_normals = tgt->cloud->normals_d;
+        A.nvdt = nf->nvdt;
+        A.ndt = nf->ndt;
+        A.compare_normals = nf->compare_normals ? 1u : 0u;
+        const bool multi = A.src.levels > 1 || A.tgt.levels > 1;
+        g_last_step_kernel = multi ? "icp_step_normal_kernel<multi-level>" : "icp_step_normal_kernel";
+#define LAUNCH_NORMAL(KC)                                                                                  \
+    do {                                                                                                   \
+        if (multi)                                                                                         \
+            hipLaunchKernelGGL((icp_step_normal_kernel<KC, true>), dim3(nb), dim3(256), 0, ctx->stream, A);  \
+        else                                                                                               \
+            hipLaunchKernelGGL((icp_step_normal_kernel<KC, false>), dim3(nb), dim3(256), 0, ctx->stream, A); \
+    } while (0)
+        ProfScope ps(ctx, PCR_PROF_STEP);
+        if (k <= 4)
+            LAUNCH_NORMAL(4);
+        else if (k <= 8)
+            LAUNCH_NORMAL(8);
+        else
+            LAUNCH_NORMAL(32);
+#undef LAUNCH_NORMAL
+        PCR_HIP(hipGetLastError());
+        return PCR_OK;  // (folded by the kernel's last blocks: the tickets are always there on this path)
+    }
     hipLaunchKernelGGL(set_args_kernel, dim3(1), dim3(256), 0, ctx->stream, A, &sc_d->args);
     launch_step_kernels(ctx, src, A, nb, k, partials_d, &sc_d->args);
     PCR_HIP(hipGetLastError());
     return PCR_OK;
 }
 
-int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const uint32_t *sample_idx_d,
-                   uint32_t sample_begin, uint32_t m, const double R[9], const double T[3], uint32_t k,
-                   double thr_fwd_sq, double thr_rev_sq, uint32_t flags, double *partials_d, uint32_t *out_fwd_d,
-                   uint32_t *out_rev_d, uint8_t *out_keep_d) {
+static int step_d_impl(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const uint32_t *sample_idx_d,
+                       uint32_t sample_begin, uint32_t m, const double R[9], const double T[3], uint32_t k,
+                       double thr_fwd_sq, double thr_rev_sq, uint32_t flags, double *partials_d, uint32_t *out_fwd_d,
+                       uint32_t *out_rev_d, uint8_t *out_keep_d, const NormalFit *nf) {
     PCR_REQUIRE(ctx && src && tgt && R && T && partials_d, "pcr_icp_step_d: NULL argument");
     PCR_HIP(hipSetDevice(ctx->device));
     const uint32_t nb = m ? (m + 255) / 256 : 0;
@@ -1010,7 +1139,16 @@ int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
     double *gp_d = (double *)((char *)tickets_d + fold_tickets_bytes(nb));
     PCR_HIP(hipMemsetAsync(tickets_d, 0, fold_tickets_bytes(nb), ctx->stream));
     return step_enqueue(ctx, src, tgt, sample_idx_d, sample_begin, m, R, T, k, thr_fwd_sq, thr_rev_sq, flags, partials_d,
-                        out_fwd_d, out_rev_d, out_keep_d, dyn_d, gp_d, tickets_d, ctx->block_partials_d, "pcr_icp_step_d");
+                        out_fwd_d, out_rev_d, out_keep_d, dyn_d, gp_d, tickets_d, ctx->block_partials_d,
+                        nf ? "pcr_icp_step_normal_fit" : "pcr_icp_step_d", nf);
+}
+
+int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const uint32_t *sample_idx_d,
+                   uint32_t sample_begin, uint32_t m, const double R[9], const double T[3], uint32_t k,
+                   double thr_fwd_sq, double thr_rev_sq, uint32_t flags, double *partials_d, uint32_t *out_fwd_d,
+                   uint32_t *out_rev_d, uint8_t *out_keep_d) {
+    return step_d_impl(ctx, src, tgt, sample_idx_d, sample_begin, m, R, T, k, thr_fwd_sq, thr_rev_sq, flags, partials_d,
+                       out_fwd_d, out_rev_d, out_keep_d, nullptr);
 }
 
 // ---- the entry point that allocates nothing (include/pcr.h: pcr_icp_step_noalloc_d) ------------------------------
@@ -1059,9 +1197,10 @@ int pcr_icp_step_noalloc_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *
                         "pcr_icp_step_noalloc_d");
 }
 
-int pcr_icp_step(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const uint32_t *sample_idx, uint32_t m,
-                 const double R[9], const double T[3], uint32_t k, double thr_fwd_sq, double thr_rev_sq,
-                 uint32_t flags, double partials[17], uint32_t *out_fwd, uint32_t *out_rev, uint8_t *out_keep) {
+static int step_host_impl(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const uint32_t *sample_idx, uint32_t m,
+                          const double R[9], const double T[3], uint32_t k, double thr_fwd_sq, double thr_rev_sq,
+                          uint32_t flags, double partials[17], uint32_t *out_fwd, uint32_t *out_rev, uint8_t *out_keep,
+                          const NormalFit *nf) {
     PCR_REQUIRE(ctx && src && tgt && partials, "pcr_icp_step: NULL argument");
     if (!sample_idx) PCR_REQUIRE(m == src->n, "pcr_icp_step: sample_idx NULL means every source point: m must be %u", src->n);
     PCR_HIP(hipSetDevice(ctx->device));
@@ -1083,8 +1222,7 @@ int pcr_icp_step(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const
     if (e == hipSuccess && out_rev && nout) e = hipMalloc(&r_d, sizeof(uint32_t) * nout);
     if (e == hipSuccess && out_keep && nout) e = hipMalloc(&k_d, nout);
     if (e == hipSuccess) {
-        rc = pcr_icp_step_d(ctx, src, tgt, s_d, 0, m, R, T, k, thr_fwd_sq, thr_rev_sq, flags, ctx->result_d, f_d, r_d,
-                            k_d);
+        rc = step_d_impl(ctx, src, tgt, s_d, 0, m, R, T, k, thr_fwd_sq, thr_rev_sq, flags, ctx->result_d, f_d, r_d, k_d, nf);
         if (rc == PCR_OK) {
             e = hipMemcpyAsync(ctx->result_h, ctx->result_d, sizeof(double) * 17, hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess && f_d) e = hipMemcpyAsync(out_fwd, f_d, sizeof(uint32_t) * nout, hipMemcpyDeviceToHost, ctx->stream);
@@ -1101,6 +1239,26 @@ int pcr_icp_step(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const
     if (rc != PCR_OK) return rc;
     PCR_HIP(e);
     return PCR_OK;
+}
+
+int pcr_icp_step(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const uint32_t *sample_idx, uint32_t m,
+                 const double R[9], const double T[3], uint32_t k, double thr_fwd_sq, double thr_rev_sq,
+                 uint32_t flags, double partials[17], uint32_t *out_fwd, uint32_t *out_rev, uint8_t *out_keep) {
+    return step_host_impl(ctx, src, tgt, sample_idx, m, R, T, k, thr_fwd_sq, thr_rev_sq, flags, partials, out_fwd, out_rev,
+                          out_keep, nullptr);
+}
+
+int pcr_icp_step_normal_fit(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const uint32_t *sample_idx,
+                            uint32_t m, const double R[9], const double T[3], uint32_t k, double nvdt, double ndt,
+                            int compare_normals, double partials[17], uint32_t *out_tgt, uint8_t *out_keep) {
+    PCR_REQUIRE(ctx && src && tgt && partials, "pcr_icp_step_normal_fit: NULL argument");
+    PCR_REQUIRE(src->kind == PCR_INDEX_GRID && tgt->kind == PCR_INDEX_GRID, "pcr_icp_step_normal_fit: grid indices only");
+    PCR_REQUIRE(tgt->cloud->normals_d, "pcr_icp_step_normal_fit: the target cloud has no normals (pcr_cloud_set_normals)");
+    PCR_REQUIRE(!compare_normals || src->cloud->normals_d,
+                "pcr_icp_step_normal_fit: comparing normals needs the source cloud's (pcr_cloud_set_normals)");
+    PCR_REQUIRE(nvdt == nvdt && ndt == ndt, "pcr_icp_step_normal_fit: a threshold is NaN");
+    const NormalFit nf = {nvdt, ndt, compare_normals};
+    return step_host_impl(ctx, src, tgt, sample_idx, m, R, T, k, 0.0, 0.0, 0, partials, out_tgt, nullptr, out_keep, &nf);
 }
 
 int pcr_reduce_pairs(pcr_ctx *ctx, const double *pair_p, const double *pair_q, uint32_t P, const double pivot_p[3],

@@ -161,6 +161,8 @@ struct pcr_cloud {
     const double *xyz_d;  // AoS [3n]
     bool owned;
     double lo[3], hi[3];
+    const double *normals_d;  // AoS [3n], original order; NULL unless attached (pcr_cloud_set_normals: the normal-aware variant)
+    bool normals_owned;
 };
 
 struct pcr_index {

@@ -18,7 +18,8 @@ struct SDeviceCloud {
     pcr_index *pIndex;
     unsigned int NumPoints;
     const double *pHostPos;
-    SDeviceCloud() : pCloud(NULL), pIndex(NULL), NumPoints(0), pHostPos(NULL) {}
+    mutable bool NormalsAttached;  // the cloud's normals are on the device (the opt-in normal-aware correspondences)
+    SDeviceCloud() : pCloud(NULL), pIndex(NULL), NumPoints(0), pHostPos(NULL), NormalsAttached(false) {}
 };
 
 class CDeviceSession {

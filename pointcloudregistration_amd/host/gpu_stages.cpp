@@ -137,8 +137,11 @@ void SDeviceStepResult::materialise() {
     std::vector<unsigned int> Fwd(M);
     std::vector<unsigned char> Keep(M);
     double Again[17];
-    const int Status = pcr_icp_step(pSession->context(), pSrc->pIndex, pTgt->pIndex, All ? NULL : SampleIdx.data(), M, R.data(),
-                                    T.data(), K, ThrFwd, ThrRev, 0u, Again, Fwd.data(), NULL, Keep.data());
+    const int Status =
+        NormalFit ? pcr_icp_step_normal_fit(pSession->context(), pSrc->pIndex, pTgt->pIndex, All ? NULL : SampleIdx.data(), M,
+                                            R.data(), T.data(), K, NVDT, NDT, CompareNormals, Again, Fwd.data(), Keep.data())
+                  : pcr_icp_step(pSession->context(), pSrc->pIndex, pTgt->pIndex, All ? NULL : SampleIdx.data(), M, R.data(),
+                                 T.data(), K, ThrFwd, ThrRev, 0u, Again, Fwd.data(), NULL, Keep.data());
     if (Status != PCR_OK) {
         warn(__EXCEPTION_SITE__, "pcr_icp_step (materialise)", Status);
         return;
@@ -197,6 +200,12 @@ CCorrespondenceEstimationClosestPointsGPU::CCorrespondenceEstimationClosestPoint
     pConfig->dumpValue(getKeyNumNeighbors(), m_NumNeighbors);
     pConfig->dumpValue(getKeySquareDistFactorThreshold(), m_SquareDistFactorThreshold);
     pConfig->dumpValue(getKeyNeighbourDistFactorThreshold(), m_NeighbourDistFactorThreshold);
+    pConfig->setIfNotExist(getKeyNormalDeviationThreshold(), 0.85);     // (:30)
+    pConfig->setIfNotExist(getKeyNormalVectorDistThreshold(), 0.0125);  // (:31)
+    pConfig->setIfNotExist(getKeyNormalFit(), 0);
+    pConfig->dumpValue(getKeyNormalDeviationThreshold(), m_NormalDeviationThreshold);
+    pConfig->dumpValue(getKeyNormalVectorDistThreshold(), m_NormalVectorDistThreshold);
+    pConfig->dumpValue(getKeyNormalFit(), m_NormalFit);
     _letFactoryReleaseProduct();
 }
 
@@ -252,7 +261,28 @@ void CCorrespondenceEstimationClosestPointsGPU::_determineCorrespondencesV(const
 
     const unsigned int World = pSession->world();
     int Status;
-    if (World == 1 && Identity) {
+    if (m_NormalFit) {  // opt-in: __insertFitPairs decides the pairs (:128-175)
+        pStep->NormalFit = true;
+        pStep->NVDT = m_NormalVectorDistThreshold;
+        pStep->NDT = m_NormalDeviationThreshold;
+        pStep->CompareNormals = m_NormalFit >= 2;
+        Status = PCR_OK;
+        if (!pTgt->NormalsAttached) {
+            Status = pcr_cloud_set_normals(pTgt->pCloud, m_pTargetPointCloud->getNormalPointer());
+            pTgt->NormalsAttached = Status == PCR_OK && m_pTargetPointCloud->getNormalPointer();
+        }
+        if (Status == PCR_OK && !pSrc->NormalsAttached) {
+            Status = pcr_cloud_set_normals(pSrc->pCloud, m_pSourcePointCloud->getNormalPointer());
+            pSrc->NormalsAttached = Status == PCR_OK && m_pSourcePointCloud->getNormalPointer();
+        }
+        unsigned int Begin = 0, Count = (unsigned int)Indices.size();
+        if (World > 1) shardRange((unsigned int)Indices.size(), pSession->rank(), World, Begin, Count);
+        if (Status == PCR_OK)
+            Status = pcr_icp_step_normal_fit(pSession->context(), pSrc->pIndex, pTgt->pIndex,
+                                             (World == 1 && Identity) ? NULL : Indices.data() + Begin, Count, vR.data(), vT.data(),
+                                             m_NumNeighbors, pStep->NVDT, pStep->NDT, pStep->CompareNormals, pStep->Partials,
+                                             NULL, NULL);
+    } else if (World == 1 && Identity) {
         Status = pcr_icp_step(pSession->context(), pSrc->pIndex, pTgt->pIndex, NULL, pSrc->NumPoints, vR.data(), vT.data(),
                               m_NumNeighbors, pStep->ThrFwd, pStep->ThrRev, 0u, pStep->Partials, NULL, NULL, NULL);
     } else {

@@ -30,8 +30,13 @@ struct SDeviceStepResult {
     const hivePointCloud::CPointCloud *pSource, *pTarget;
     std::vector<unsigned int> SampleIdx;  // empty = every source point
     bool Materialised;
+    bool NormalFit;  // the opt-in normal-aware pair decision made these pairs (NVDT, NDT, CompareNormals)
+    double NVDT, NDT;
+    int CompareNormals;
     VecColVector3 SrcPoints, SrcNormals, TgtPoints, TgtNormals;
-    SDeviceStepResult() : K(0), ThrFwd(0), ThrRev(0), pSource(NULL), pTarget(NULL), Materialised(false) {}
+    SDeviceStepResult()
+        : K(0), ThrFwd(0), ThrRev(0), pSource(NULL), pTarget(NULL), Materialised(false), NormalFit(false), NVDT(0), NDT(0),
+          CompareNormals(0) {}
     void materialise();  // re-runs the step with index outputs and gathers the kept pairs, in sample order
 };
 
@@ -121,6 +126,13 @@ public:
     static std::string getKeyNumNeighbors() { return toUpperCopy("CorrespondenceEstimationClosestPoints.NN"); }
     static std::string getKeySquareDistFactorThreshold() { return toUpperCopy("CorrespondenceEstimationClosestPoints.SDFT"); }
     static std::string getKeyNeighbourDistFactorThreshold() { return toUpperCopy("CorrespondenceEstimationClosestPoints.NDFT"); }
+    static std::string getKeyNormalDeviationThreshold() { return toUpperCopy("CorrespondenceEstimationClosestPoints.NDT"); }
+    static std::string getKeyNormalVectorDistThreshold() { return toUpperCopy("CorrespondenceEstimationClosestPoints.NVDT"); }
+    // OPT-IN (no reference counterpart as a switch: the reference comments the call out, :105): 1 = pairs are decided by
+    // __insertFitPairs (:128-175) instead of the reciprocal gate; 2 = and normals are compared too (NDT; the reference
+    // hard-wires NoNormalCompare).  Both clouds must carry normals.  Runs stage by stage, not in the fused device loop.
+    static std::string getKeyNormalFit() { return toUpperCopy("CorrespondenceEstimationClosestPointsGPU.NORMALFIT"); }
+    bool usesNormalFit() const { return m_NormalFit != 0; }
 
 protected:
     virtual ~CCorrespondenceEstimationClosestPointsGPU() {}
@@ -131,6 +143,8 @@ protected:
 private:
     unsigned int m_NumNeighbors;
     double m_SquareDistFactorThreshold, m_NeighbourDistFactorThreshold;
+    int m_NormalFit;
+    double m_NormalDeviationThreshold, m_NormalVectorDistThreshold;
 };
 
 class CCorrespondenceRejectionClosestPoints : public CBaseCorrespondenceRejection {

@@ -174,7 +174,8 @@ bool CIterativeFit::__fitLoopFused(Eigen::Matrix3d &vioR, ColVector3 &vioT) {
     PTR_CONTROL_PARAMS->dumpValue(getKeyFusedLoop(), Fused);
     pcrhost::CDeviceSession *pSession = pcrhost::CDeviceSession::getInstance();
     if (!Fused || pSession->world() > 1) return false;  // sharded runs reduce through the host hook, stage by stage
-    if (!dynamic_cast<CCorrespondenceEstimationClosestPointsGPU *>(m_pCorrespondenceEstimation) ||
+    CCorrespondenceEstimationClosestPointsGPU *pClosest = dynamic_cast<CCorrespondenceEstimationClosestPointsGPU *>(m_pCorrespondenceEstimation);
+    if (!pClosest || pClosest->usesNormalFit() ||  // (the opt-in normal-aware pairs run stage by stage)
         !dynamic_cast<CCorrespondenceRejectionClosestPoints *>(m_pCorrespondenceRejection) ||
         !dynamic_cast<CTransformationEstimationSVD2GPU *>(m_pTransformationEsitmation))
         return false;

@@ -157,3 +157,23 @@ def test_reject_centroid_dist_golden_and_quirks(oracle):
     c = y + p["src"][nb].sum(0)
     c[0] = c[0] / 26 / 26 / 26
     assert abs(abs(s_t - ((y - c) ** 2).sum()) - g["default_d"][0]) <= 1e-9 * g["default_d"][0]
+
+
+def test_normal_fit_restatement_by_hand(oracle):
+    """f4 (__insertFitPairs, :128-175): the first of the K neighbours whose direction from the sample is parallel to its
+    own normal wins; the nearest one is passed over when its normal is not; no neighbour qualifying = no pair."""
+    tgt = np.array([[0.0, 0.0, 0.0], [0.3, 0.0, 0.0], [5.0, 5.0, 5.0], [9.0, 9.0, 9.0]])
+    tn = np.array([[1.0, 0.0, 0.0], [0.0, 0.0, 2.0], [0.0, 3.0, 0.0], [1.0, 1.0, 1.0]])   # not unit length on purpose
+    src = np.array([[0.1, 0.0, 0.4],      # nearest 0 (normal x: direction is mostly z -> refused), then 1: (0.2,0,-0.4).z -> |cos| 0.894
+                    [0.3, 0.0, 0.7],      # nearest 1, straight above it along its normal: accepted at once
+                    [5.0, 4.0, 5.0]])     # nearest 2, along its normal y
+    sn = np.array([[0.0, 0.0, 1.0]] * 3)
+    eye, zero = np.eye(3).reshape(9), np.zeros(3)
+    tree = oracle.KdOld(tgt, 2)
+    r = oracle.icrp_normal_fit(src, sn, tgt, tn, tree, eye, zero, 2, nvdt=0.0125)
+    assert list(r["tgt"]) == [0xFFFFFFFF, 1, 2] and list(r["keep"]) == [0, 1, 1] and r["P"] == 2
+    r = oracle.icrp_normal_fit(src, sn, tgt, tn, tree, eye, zero, 2, nvdt=0.2)       # 1 - 0.894 < 0.2: the SECOND neighbour
+    assert list(r["tgt"]) == [1, 1, 2]
+    r = oracle.icrp_normal_fit(src, sn, tgt, tn, tree, eye, zero, 2, nvdt=0.2, ndt=0.85, compare_normals=True)
+    assert list(r["tgt"]) == [1, 1, 0xFFFFFFFF]   # sample 2's normal z against the neighbour's normal y: |cos| = 0 <= NDT
+    np.testing.assert_array_equal(r["pair_q"], tgt[[1, 1]])
