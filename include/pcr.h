@@ -161,6 +161,11 @@ int pcr_unique_sq_dist(pcr_ctx *ctx, const pcr_index *index, double *out);
  * do not fit. */
 int pcr_sample_random(pcr_ctx *ctx, uint32_t n, double ratio, uint64_t seed, uint32_t cap, uint32_t *out_idx,
                       uint32_t *out_count);
+/* CSamplerRandom's rule on a rand() stream of the CALLER's (SamplerRandom.cpp:45-48 with ICPMacros.h:4): point i is kept
+ * iff (double)draws[i] / (rand_max + 1) < ratio, draws[i] = the i-th value rand() returned, rand_max = that generator's
+ * RAND_MAX (32767 for the reference's MSVC runtime).  Given the stream, the reference's sample set index for index. */
+int pcr_sample_random_draws(pcr_ctx *ctx, uint32_t n, double ratio, const int32_t *draws, uint32_t rand_max, uint32_t cap,
+                            uint32_t *out_idx, uint32_t *out_count);
 int pcr_sample_grid(pcr_ctx *ctx, const pcr_index *index, uint32_t cap, uint32_t *out_idx, uint32_t *out_count);
 
 /* ---- one ICRP iteration ------------------------------------------------------------

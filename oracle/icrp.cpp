@@ -178,6 +178,16 @@ uint32_t orc_icrp_correspondences(const double *src, uint32_t ns, const double *
     return P;
 }
 
+// CSamplerRandom::_doSampleV (Sampler/SamplerRandom.cpp:25-51) on an explicit stream of rand() values: the loop
+// `for i: if (ICP_RAND(0.0, 1.0) < SampleRatio) push_back(i)` with ICP_RAND(min, max) = (min) + (double)rand()/(RAND_MAX+1)
+// *((max)-(min)) (ICPMacros.h:4).  The reference never seeds rand(); whoever supplies the stream decides it.
+uint32_t orc_sampler_random(const int32_t *draws, uint32_t n, uint32_t rand_max, double ratio, uint32_t *out_idx) {
+    uint32_t c = 0;
+    for (uint32_t i = 0; i < n; ++i)
+        if ((0.0) + (double)draws[i] / ((double)rand_max + 1.0) * ((1.0) - (0.0)) < ratio) out_idx[c++] = i;
+    return c;
+}
+
 // Eigen's Vector3d::normalize() of the reference's vintage: *this /= sqrt(squaredNorm()), no zero test (a zero
 // vector becomes NaN); squaredNorm and dot sum left to right.
 static inline void normalize3(double v[3]) {

@@ -236,6 +236,16 @@ class Convergence:
             self.h = None
 
 
+def sampler_random(draws, ratio, rand_max=32767):
+    d = np.ascontiguousarray(draws, np.int32)
+    out = np.empty(len(d), np.uint32)
+    fn = lib().orc_sampler_random
+    fn.restype = C.c_uint32
+    fn.argtypes = [C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.c_double, _up]
+    c = fn(d.ctypes.data_as(C.POINTER(C.c_int32)), len(d), rand_max, ratio, _u(out))
+    return out[:c].copy()
+
+
 def icrp_normal_fit(src, src_normals, tgt, tgt_normals, tree, R, T, k, nvdt=0.0125, ndt=0.85, compare_normals=False,
                     sample_idx=None, threads=1):
     """f4 (opt-in): __insertFitPairs as the pair decision; see icrp.cpp."""

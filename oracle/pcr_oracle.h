@@ -63,6 +63,9 @@ uint32_t orc_icrp_correspondences(const double *src, uint32_t ns, const double *
                                   uint32_t *rev, uint8_t *keep, double *pair_p, double *pair_q,
                                   int threads);
 
+/* CSamplerRandom::_doSampleV (Sampler/SamplerRandom.cpp:25-51) on a caller-supplied stream of rand() values. */
+uint32_t orc_sampler_random(const int32_t *draws, uint32_t n, uint32_t rand_max, double ratio, uint32_t *out_idx);
+
 /* f4, opt-in: __insertFitPairs (CorrespondenceEstimationClosestPoints.cpp:128-175) as the pair decision, with
  * TmpTgtPoint := the neighbour's position (the reference reads it unassigned: undefined behaviour there).
  * out_tgt[m]: the chosen target index or ORC_NO_INDEX.  Returns the number of pairs. */

@@ -69,6 +69,7 @@ SYMBOLS = {
     "pcr_knn_d": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_int, C.c_double, _vp, _vp]),
     "pcr_unique_sq_dist": (C.c_int, [_vp, _vp, _dp]),
     "pcr_sample_random": (C.c_int, [_vp, C.c_uint32, C.c_double, C.c_uint64, C.c_uint32, _up, _up]),
+    "pcr_sample_random_draws": (C.c_int, [_vp, C.c_uint32, C.c_double, C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, _up, _up]),
     "pcr_sample_grid": (C.c_int, [_vp, _vp, C.c_uint32, _up, _up]),
     "pcr_icp_step": (C.c_int, [_vp, _vp, _vp, _up, C.c_uint32, _dp, _dp, C.c_uint32, C.c_double, C.c_double,
                                C.c_uint32, _dp, _up, _up, _bp]),
@@ -357,6 +358,16 @@ def sample_random(ctx, n, ratio, seed=0):
     out = np.empty(max(n, 1), np.uint32)
     cnt = C.c_uint32(0)
     _check(lib().pcr_sample_random(ctx.h, n, ratio, seed, n, _u(out), C.byref(cnt)), "pcr_sample_random")
+    return out[:cnt.value].copy()
+
+
+def sample_random_draws(ctx, ratio, draws, rand_max=32767):
+    """CSamplerRandom's rule on the caller's rand() stream (one draw per point)."""
+    d = np.ascontiguousarray(draws, np.int32)
+    out = np.empty(len(d), np.uint32)
+    cnt = C.c_uint32(0)
+    _check(lib().pcr_sample_random_draws(ctx.h, len(d), ratio, d.ctypes.data_as(C.POINTER(C.c_int32)), rand_max, len(d),
+                                         _u(out), C.byref(cnt)), "pcr_sample_random_draws")
     return out[:cnt.value].copy()
 
 

@@ -5,6 +5,8 @@
 //                      u_i is a counter-based hash of (seed, i), so a sample set is a pure function of its seed --
 //                      reproducible, order-independent, and parallel.  Same distribution, not the same stream:
 //                      there is no stream to reproduce ("parity unpinned" by construction of the reference).
+//   pcr_sample_random_draws  the same rule on a stream of rand() values the caller drew: given the stream, the sample set
+//                      is the reference's index for index (checked against the oracle's restatement).
 //   pcr_sample_grid    the uniform-grid sampler the reference only stubs (Sampler/SamplerUniformGrid.cpp:25-28):
 //                      one point per occupied cell of the index's grid -- the cell's first point in layout order
 //                      (smallest x, ties by index), free once the index exists.
@@ -27,6 +29,15 @@ struct RandomPick {
     uint64_t seed;
     double ratio;
     __device__ bool keep(uint64_t i) const { return hash_uniform(seed, i) < ratio; }
+    __device__ uint32_t value(uint64_t i) const { return (uint32_t)i; }
+};
+// CSamplerRandom's rule on a stream of rand() values the CALLER drew (ICPMacros.h:4: (double)rand() / (RAND_MAX + 1)):
+// with the stream given, the sample set is the reference's, index for index
+struct DrawPick {
+    const int32_t *draws;  // device, [n]
+    double denom;          // RAND_MAX + 1
+    double ratio;
+    __device__ bool keep(uint64_t i) const { return 0.0 + (double)draws[i] / denom * (1.0 - 0.0) < ratio; }
     __device__ uint32_t value(uint64_t i) const { return (uint32_t)i; }
 };
 struct CellPick {
@@ -129,6 +140,24 @@ int pcr_sample_random(pcr_ctx *ctx, uint32_t n, double ratio, uint64_t seed, uin
     PCR_REQUIRE(ratio >= 0.0 && ratio <= 1.0, "pcr_sample_random: ratio %g outside [0,1]", ratio);
     PCR_HIP(hipSetDevice(ctx->device));
     return pick_compact(ctx, RandomPick{seed, ratio}, n, cap, out_idx, out_count, false);
+}
+
+int pcr_sample_random_draws(pcr_ctx *ctx, uint32_t n, double ratio, const int32_t *draws, uint32_t rand_max, uint32_t cap,
+                            uint32_t *out_idx, uint32_t *out_count) {
+    PCR_REQUIRE(ctx && out_idx && out_count && (draws || n == 0), "pcr_sample_random_draws: NULL argument");
+    PCR_REQUIRE(ratio >= 0.0 && ratio <= 1.0, "pcr_sample_random_draws: ratio %g outside [0,1]", ratio);
+    PCR_REQUIRE(rand_max >= 1, "pcr_sample_random_draws: rand_max must be RAND_MAX of the generator that drew the stream");
+    PCR_HIP(hipSetDevice(ctx->device));
+    *out_count = 0;
+    if (n == 0) return PCR_OK;
+    int32_t *d = nullptr;
+    PCR_HIP(hipMalloc(&d, sizeof(int32_t) * (size_t)n));
+    hipError_t e = hipMemcpyAsync(d, draws, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
+    int rc = PCR_OK;
+    if (e == hipSuccess) rc = pick_compact(ctx, DrawPick{d, (double)rand_max + 1.0, ratio}, n, cap, out_idx, out_count, false);
+    hipFree(d);
+    PCR_HIP(e);
+    return rc;
 }
 
 int pcr_sample_grid(pcr_ctx *ctx, const pcr_index *index, uint32_t cap, uint32_t *out_idx, uint32_t *out_count) {

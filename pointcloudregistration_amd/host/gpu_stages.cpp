@@ -1,5 +1,6 @@
 #include "gpu_stages.h"
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 
 using namespace hiveRegistration;
@@ -94,7 +95,17 @@ CorrespondencePointSet CSamplerRandomGPU::_doSampleV(const hivePointCloud::CPoin
     }
     std::vector<unsigned int> Indices(NumPnt);
     uint32_t Count = 0;
-    const int Status = pcr_sample_random(pSession->context(), (uint32_t)NumPnt, Ratio, Seed, (uint32_t)NumPnt, Indices.data(), &Count);
+    int UseRand = 0;
+    PTR_CONTROL_PARAMS->dumpValue(getKeyUseRand(), UseRand);
+    int Status;
+    if (UseRand) {
+        std::vector<int32_t> Draws(NumPnt);
+        for (int i = 0; i < NumPnt; ++i) Draws[i] = rand();  // ICP_RAND's rand(), once per point, in order (ICPMacros.h:4)
+        Status = pcr_sample_random_draws(pSession->context(), (uint32_t)NumPnt, Ratio, Draws.data(), (uint32_t)RAND_MAX,
+                                         (uint32_t)NumPnt, Indices.data(), &Count);
+    } else {
+        Status = pcr_sample_random(pSession->context(), (uint32_t)NumPnt, Ratio, Seed, (uint32_t)NumPnt, Indices.data(), &Count);
+    }
     if (Status != PCR_OK) {
         warn(__EXCEPTION_SITE__, "pcr_sample_random", Status);
         return CorrespondencePointSet();

@@ -100,6 +100,10 @@ public:
     static std::string getKeySampleNum() { return toUpperCopy("SamplerRandom.SN"); }
     static std::string getKeySampleRatio() { return toUpperCopy("SamplerRandom.SR"); }
     static std::string getKeySeed() { return toUpperCopy("SamplerRandom.Seed"); }
+    // 1: draw with the host's rand() -- one call per point, in point order, exactly as the reference's loop does
+    // (SamplerRandom.cpp:45-48) -- and apply its rule to that stream on the device: with the same C runtime and the same
+    // rand() state the sample set is the reference's, index for index.  0 (default): the seeded counter hash.
+    static std::string getKeyUseRand() { return toUpperCopy("SamplerRandomGPU.USERAND"); }
 
 protected:
     virtual CorrespondencePointSet _doSampleV(const hivePointCloud::CPointCloud &vPointCloud);

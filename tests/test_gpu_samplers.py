@@ -67,3 +67,50 @@ def test_samplers_behind_the_plugin_interface():
     d = hostapi.fit(src, tgt, R0=R0, T0=T0, sampler="SamplerRandomGPU")
     assert d["iterations"] == 0 and d["msg"] == "Point Cloud Not Valid!"
     hostapi.reset()
+
+
+def test_random_sampler_rule_on_a_given_rand_stream_equals_the_oracle(pcr, ctx, oracle):
+    """CSamplerRandom's rule (SamplerRandom.cpp:45-48, ICPMacros.h:4) on a rand() stream supplied by the caller: the
+    sample set is then determined, and the GPU compaction must return the restatement's indices exactly -- for the
+    reference's MSVC RAND_MAX (32767) and for glibc's (2^31 - 1), at the ratios where draws tie with the threshold."""
+    rng = np.random.default_rng(11)
+    for rand_max, n in ((32767, 300000), (2147483647, 70001)):
+        draws = rng.integers(0, rand_max + 1, n, dtype=np.int64).astype(np.int32)
+        for ratio in (0.0, 0.05, 0.25, 16384 / 32768.0, 0.999, 1.0):
+            got = pcr.sample_random_draws(ctx, ratio, draws, rand_max)
+            want = oracle.sampler_random(draws, ratio, rand_max)
+            assert len(got) == len(want) and (got == want).all(), (rand_max, ratio)
+        assert abs(len(pcr.sample_random_draws(ctx, 0.25, draws, rand_max)) - 0.25 * n) < 5 * np.sqrt(n)
+    assert len(pcr.sample_random_draws(ctx, 0.5, np.zeros(0, np.int32))) == 0
+
+
+def test_plugin_random_sampler_on_the_hosts_rand_stream_equals_the_oracle_fit(oracle):
+    """SamplerRandomGPU.USERAND = 1: the plugin draws rand() once per point in point order, as the reference's loop does,
+    and applies the reference's rule -- so with the C runtime's generator in a known state the sample set, and with it
+    the whole fit, is determined: it must equal the oracle's fit over the oracle's samples from the same stream."""
+    import ctypes
+    from pointcloudregistration_amd import hostapi, synth
+    libc = ctypes.CDLL(None)
+    libc.rand.restype = ctypes.c_int
+    n = 30000
+    src, tgt, Rm, t = synth.registration_pair(n, n, 9)
+    R0, T0 = synth.coarse_initial_transform(Rm, t, n)
+    libc.srand(4711)
+    draws = np.array([libc.rand() for _ in range(n)], np.int32)
+    smp = oracle.sampler_random(draws, 0.2, 2147483647)
+    assert abs(len(smp) - 0.2 * n) < 5 * np.sqrt(n)
+    want = oracle.fit(src, tgt, k=4, sdft=36.0, ndft=4.0, conv=oracle.ConvParams.regcfg(30), R0=R0, T0=T0, sample_idx=smp)
+    hostapi.reset()
+    try:
+        hostapi.config_text("BaseConvergenceCriteria.MI = 30\nDefaultConvergenceCriteria.AMSE = 0.01\nDefaultConvergenceCriteria.RMSE = 0.01\n"
+                            "DefaultConvergenceCriteria.RT = 0.000001\nDefaultConvergenceCriteria.TT = 0.0000001\n"
+                            "CorrespondenceEstimationClosestPoints.SDFT = 36.0\nCorrespondenceEstimationClosestPoints.NDFT = 4.0\n"
+                            "SamplerRandom.SR = 0.2\nSamplerRandomGPU.USERAND = 1\n")
+        libc.srand(4711)
+        got = hostapi.fit(src, tgt, R0=R0, T0=T0, sampler="SamplerRandomGPU")
+        assert got["status"] == 0 and got["iterations"] == want["iterations"]
+        assert (got["traj"][:, 13] == np.asarray(want["traj"])[:, 13]).all()   # the same samples -> the same pair counts
+        np.testing.assert_allclose(got["R"], want["R"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(got["T"], want["T"], rtol=0, atol=1e-9)
+    finally:
+        hostapi.reset()

@@ -20,12 +20,13 @@ def main():
     ap.add_argument("--outliers", type=float, default=0.3)
     ap.add_argument("--k", type=int, default=4)
     ap.add_argument("--occupancy", type=float, default=0.0, help="index target occupancy (0: library default)")
+    ap.add_argument("--max-cells", type=int, default=0, help="cap on a level's cell table (0: library default)")
     a = ap.parse_args()
     from pointcloudregistration_amd import capi as pcr, synth
     src, tgt, Rm, t = synth.lidar_pair(a.n, 516, outlier_frac=a.outliers)
     ctx = pcr.Context(0)
-    six = pcr.Index(ctx, pcr.Cloud(ctx, src), target_occupancy=a.occupancy)
-    tix = pcr.Index(ctx, pcr.Cloud(ctx, tgt), target_occupancy=a.occupancy)
+    six = pcr.Index(ctx, pcr.Cloud(ctx, src), target_occupancy=a.occupancy, max_cells=a.max_cells)
+    tix = pcr.Index(ctx, pcr.Cloud(ctx, tgt), target_occupancy=a.occupancy, max_cells=a.max_cells)
     U = tix.unique_sq_dist()
     R, T = synth.colmajor(Rm), t
     pcr.icp_step(ctx, six, tix, R, T, a.k, U * 36.0, U * 4.0, exact=False, want_outputs=False)   # warm-up
