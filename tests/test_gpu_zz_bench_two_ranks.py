@@ -13,10 +13,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(extra_env, launcher, extra_args):
+def _bench(extra_env, launcher, extra_args, knn=False):
     env = dict(os.environ, **extra_env)
     cmd = [sys.executable] + launcher + [os.path.join(ROOT, "bench.py"), "--points", "200000", "--steps", "6", "--warmup", "1",
-                                         "--no-cpu-baseline", "--no-knn"] + extra_args
+                                         "--no-cpu-baseline"] + ([] if knn else ["--no-knn"]) + extra_args
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
@@ -31,7 +31,9 @@ def test_two_rank_bench_adds_up_to_the_single_rank_fit():
                  ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                   "--master-port", "29577"], ["--gpus", "2"])
     # `python bench.py --gpus 2` with no launcher: bench.py starts its own ranks (and never quietly measures one GPU)
-    own = _bench({"PCR_BENCH_REHEARSE_ONE_GPU": "1"}, [], ["--gpus", "2"])
+    # (this one also runs the K-NN leg, whose query batch is sharded over the ranks)
+    own = _bench({"PCR_BENCH_REHEARSE_ONE_GPU": "1"}, [], ["--gpus", "2"], knn=True)
+    assert own["knn_queries_per_s"]["sharded_over_ranks"] == 2 and own["knn_queries_per_s"]["k4"] > 1e8
     assert own["n_gpus"] == 2 and own["fit"]["kept_pairs_last"] == two["fit"]["kept_pairs_last"]
     assert abs(own["fit"]["mse_last"] - two["fit"]["mse_last"]) <= 1e-12 * two["fit"]["mse_last"]
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["steps"] == 6
