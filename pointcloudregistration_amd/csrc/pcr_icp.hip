@@ -464,6 +464,33 @@ __global__ void __launch_bounds__(256, MULTI ? PCR_MULTI_WAVES : PCR_STEP_WAVES)
 // source: keys are taken in the SOURCE frame (q mapped back by R^-1; the key error bound is widened by R's deviation
 // from an isometry), and only the few candidates that reach the fp64 stage are moved by (R,T), with
 // CPointCloud::transform's expression.  Every index, flag and sum is bit-identical to icp_step_grid_kernel's (tested).
+// The rare lanes the filtered walk cannot vouch for repeat the search with the all-fp64 walk.  (Taking these out of
+// line -- so that the walk's registers are not part of the filtered kernel's own allocation -- removes the hot path's
+// spills but gains nothing: the kernel is bound by instruction issue, not by its 40 MB of spill traffic.)
+#ifndef PCR_FALLBACK_INLINE
+#define PCR_FALLBACK_INLINE __forceinline__  // (measured: out of line 170 us at 4 waves/SIMD, 155 at "5"; inline 153-155)
+#endif
+template <int KC>
+__device__ PCR_FALLBACK_INLINE void fallback_forward(const StepArgs *__restrict__ Ap, double px, double py, double pz, double fmax_d2,
+                                                     double fwd_scale, int k, uint2 *my_rows, double *dF, uint32_t *j) {
+    TopK<KC> top;
+    top.init(fmax_d2);
+    const GridView G = Ap->tgt.v[0];  // (through the generic pointer)
+    lane_search<KC>(G, Ap->tgt.all, px, py, pz, px, py, pz, fmax_d2, fwd_scale, 0.0, top, my_rows);
+    top.slot(k, *dF, *j);
+}
+__device__ PCR_FALLBACK_INLINE uint32_t fallback_reverse(const StepArgs *__restrict__ Ap, double qx, double qy, double qz, double sx,
+                                                         double sy, double sz, double rbs, double rem_, double dF, uint32_t orig,
+                                                         uint2 *my_rows) {
+    TopK<1> rt;
+    rt.d[0] = dF;
+    rt.idx[0] = orig;
+    const GridView G = Ap->src.v[0];
+    const Rigid M = Ap->dyn->M;
+    lane_search<1, true>(G, Ap->src.all, qx, qy, qz, sx, sy, sz, PCR_INF, rbs, rem_, rt, my_rows, &M);
+    return rt.idx[0];
+}
+
 // lb of nb: the block's place among the blocks of ITS problem (a launch may carry many: icp_step_batch_kernel)
 template <int KC>
 __device__ __forceinline__ void fast_step_body(const StepArgs *__restrict__ Ap, uint32_t lb, uint32_t nb) {
@@ -516,13 +543,7 @@ __device__ __forceinline__ void fast_step_body(const StepArgs *__restrict__ Ap, 
             fwd_done = fast_ring1<KC, false, false>(GT, GT.pts, px, py, pz, px, py, pz, fmax_d2, bound_d2, fwd_scale, 0.0,
                                                     GT.key_delta, A->k, 0.0, 0u, dF, j, my_rows, (const Rigid *)nullptr);
         if (__any(!fwd_done)) {
-            if (!fwd_done) {
-                TopK<KC> top;
-                top.init(fmax_d2);
-                const GridView G = Ap->tgt.v[0];  // (the rare path: through the generic pointer)
-                lane_search<KC>(G, Ap->tgt.all, px, py, pz, px, py, pz, fmax_d2, fwd_scale, 0.0, top, my_rows);
-                top.slot(A->k, dF, j);
-            }
+            if (!fwd_done) fallback_forward<KC>(Ap, px, py, pz, fmax_d2, fwd_scale, A->k, my_rows, &dF, &j);
         }
         found = fin && j != PCR_NO_INDEX && dF < fmax_d2;
         passF = found && dF < A->thr_fwd;  // strict < (:97)
@@ -562,15 +583,7 @@ __device__ __forceinline__ void fast_step_body(const StepArgs *__restrict__ Ap, 
             rev_done = fast_ring1<1, true, true>(GS, GS.pts, qx, qy, qz, sx, sy, sz, PCR_INF, dF, rbs, rem_, rev_delta, 1, dF,
                                                  orig, dRv, rv, my_rows, &D->M);
         if (__any(!rev_done)) {
-            if (!rev_done) {
-                TopK<1> rt;
-                rt.d[0] = dF;
-                rt.idx[0] = orig;
-                const GridView G = Ap->src.v[0];
-                const Rigid M = Ap->dyn->M;
-                lane_search<1, true>(G, Ap->src.all, qx, qy, qz, sx, sy, sz, PCR_INF, rbs, rem_, rt, my_rows, &M);
-                rv = rt.idx[0];
-            }
+            if (!rev_done) rv = fallback_reverse(Ap, qx, qy, qz, sx, sy, sz, rbs, rem_, dF, orig, my_rows);
         }
         if (need_rev) {
             r = rv;
