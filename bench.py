@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--k", type=int, default=4, help="CorrespondenceEstimationClosestPoints.NN")
     ap.add_argument("--occupancy", type=float, default=0.0, help="grid target occupancy (0 = library default)")
     ap.add_argument("--tune", type=str, default="", help="debug: comma list key=value for pcr_tune")
+    ap.add_argument("--prewarm-steps", type=int, default=600,
+                    help="untimed iterations run before the W warm-up steps so that the GPU is at its sustained clocks "
+                         "(a power-managed device needs ~0.1 s of load: 6 550 it/s after 10 iterations, 6 800 after 300)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-knn", action="store_true")
     args = ap.parse_args()
@@ -154,7 +157,7 @@ def main():
     if rehearse:
         local_rank = 0
         import faulthandler
-        faulthandler.dump_traceback_later(240, exit=True)  # a rehearsal that stalls says where
+        faulthandler.dump_traceback_later(int(os.environ.get("PCR_BENCH_DUMP_AFTER", "240")), exit=True)  # a rehearsal that stalls says where
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -175,7 +178,10 @@ def main():
     for kv in filter(None, args.tune.split(",")):
         kk, vv = kv.split("=")
         capi.lib().pcr_tune(int(kk), int(vv))
-    stream = torch.cuda.current_stream()
+    # a stream of this process's own, current for torch too: the legacy default stream orders itself against every other
+    # blocking stream of the process on each submission
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     ctx = capi.Context(local_rank, stream=stream)
     src_t = torch.from_numpy(src).to(dev)
     tgt_t = torch.from_numpy(tgt).to(dev)
@@ -243,6 +249,10 @@ def main():
                     torch.cuda.synchronize()  # gloo stages through the host: tell a stalled kernel from a stalled exchange
                 if comm is not None:
                     comm.allreduce_partials(part_ptr)
+                elif rehearse:  # gloo on a HOST tensor: its device-tensor path stalls now and then when two ranks share a GPU
+                    host = part_t.cpu()
+                    dist.all_reduce(host)
+                    part_t.copy_(host)
                 else:
                     dist.all_reduce(part_t)
             fit.solve()
@@ -253,6 +263,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # device pre-warm (not one of the W warm-up steps, not timed): the same loop, long enough for the clocks to settle
+    if args.prewarm_steps > 0 and (not rehearse or os.environ.get("PCR_BENCH_PREWARM_IN_REHEARSAL") == "1"):  # (a rehearsal's numbers mean nothing, and gloo makes every step slow)
+        fit.reset(R0, T0)
+        enqueue(args.prewarm_steps)
+        barrier()
     # warm-up: every kernel class bracketed by HIP events (the figures of the minor kernels come from here)
     fit.reset(R0, T0)
     ctx.set_profiling(True)
@@ -260,24 +275,43 @@ def main():
     enqueue(args.warmup)
     barrier()
     kt_warm = ctx.read_kernel_times()
-    # the timed fit restarts from the coarse initial transform: steps 1..K of one registration.  Only the
-    # dominant kernel is bracketed by HIP events here (on the context's stream): an event pair costs queue time.
+    # The timed fit restarts from the coarse initial transform: steps 1..K of one registration.  Nothing is bracketed per
+    # launch in here -- a HIP event pair per launch serialises the dispatches and costs 7-9 us of a ~146 us iteration
+    # (tools/bench_graph.py: 145.7 vs 153.0 us) -- ONE event pair on the kernels' stream brackets the whole region.
     fit.reset(R0, T0)
-    ctx.set_profiling(True, classes=(1,))
+    ctx.set_profiling(False)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
+    ev0.record(stream)
     enqueue(args.steps)
+    ev1.record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
-    kt = ctx.read_kernel_times()
-    ctx.set_profiling(False)
+    region_ms = ev0.elapsed_time(ev1)
     res = fit.read()
     assert res["iterations"] == args.steps, res
     R, T, mse, kept = res["R"], res["T"], res["mse"], res["pairs"]
-    if world > 1:
-        et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(et, op=dist.ReduceOp.MAX)
-        elapsed = float(et.item())
+    # the same K steps once more, untimed, every launch of the dominant kernel bracketed by its own HIP event pair: the
+    # per-launch durations rocprofv3's kernel trace is compared with (both serialise the dispatches)
+    fit.reset(R0, T0)
+    ctx.set_profiling(True, classes=(1,))
+    ctx.read_kernel_times()
+    barrier()
+    enqueue(args.steps)
+    barrier()
+    per_launch = ctx.read_kernel_launches(1)
+    kt = ctx.read_kernel_times()
+    ctx.set_profiling(False)
+    again = fit.read()
+    assert (again["R"] == R).all() and again["pairs"] == kept  # the instrumented pass did the same work
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearse else dev)  # (gloo: host tensors, see above)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    elapsed = max_over_ranks(elapsed)
 
     # registration quality of the timed fit (not part of the metric; shows the work was real)
     R_est = synth.rowcol(R)
@@ -302,10 +336,7 @@ def main():
                 b.synchronize()
                 ts.append(a.elapsed_time(b) * 1e-3)
             med = float(np.median(ts[3:]))
-            if world > 1:
-                mt = torch.tensor([med], dtype=torch.float64, device=dev)
-                dist.all_reduce(mt, op=dist.ReduceOp.MAX)
-                med = float(mt.item())
+            med = max_over_ranks(med)
             knn[f"k{kk}"] = n / med
         # 24 + 28 K algorithmic bytes per query; peak = every rank's HBM
         knn["roofline"] = {f"k{kk}": {"bound": "hbm", "achieved": knn[f"k{kk}"] * (24 + 28 * kk) / 1e9, "peak": HBM_PEAK_GBS * world,
@@ -332,7 +363,13 @@ def main():
                                "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0,
                                "algorithmic_bytes_per_pair": (24 + 28 * 25) * 2}}
     if rank == 0:
-        step_ms = kt["step"][0] / max(1, kt["step"][1])
+        # The dominant kernel's average launch duration.  One GPU: an iteration IS one launch of it (search, sums, fold,
+        # solve), so the event pair around the timed region, divided by K, bounds it from above (it includes the gaps
+        # between launches) -- measured on the un-instrumented run the headline value comes from.  N > 1: other work sits
+        # between the launches, so the per-launch event pairs of the instrumented pass are what there is.
+        per_launch_ms = kt["step"][0] / max(1, kt["step"][1])
+        single = not (world > 1 or force_dist)
+        step_ms = region_ms / args.steps if single else per_launch_ms
         algo_bytes = algorithmic_bytes_per_sample(k) * m
         achieved = algo_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
         info = tix.info()
@@ -357,7 +394,17 @@ def main():
                          "traffic_source": traffic_src,
                          "valu_insts_per_launch": valu_insts, "valu_utilisation": valu_util,
                          "kernel": capi.last_step_kernel(),
-                         "kernel_ms_avg": step_ms, "launches": kt["step"][1],
+                         "kernel_ms_avg": step_ms, "launches": args.steps,
+                         "kernel_ms_avg_source": ("one HIP event pair on the kernels' stream around the K back-to-back launches of "
+                                                  "the timed region, / K: an upper bound (gaps between launches included)"
+                                                  if single else "a HIP event pair around every launch (instrumented pass)"),
+                         "kernel_ms_avg_per_launch_events": per_launch_ms,
+                         "per_launch_events_note": "the same K steps run once more, untimed, each launch bracketed by its own "
+                                                   "event pair: dispatches are then serialised, as under rocprofv3 --kernel-trace "
+                                                   "(profiles/), which is why this figure -- not kernel_ms_avg -- matches the "
+                                                   "profile's average; tools/bench_graph.py measures the difference",
+                         "kernel_ms_first_iteration": float(per_launch[0]) if len(per_launch) else None,
+                         "prewarm_steps": args.prewarm_steps,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "other_kernels_ms_avg": {"transform": kt_warm["transform"][0] / max(1, kt_warm["transform"][1]),
                                                   "fold": kt_warm["fold"][0] / max(1, kt_warm["fold"][1]),

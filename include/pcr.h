@@ -83,10 +83,15 @@ int pcr_ctx_synchronize(pcr_ctx *ctx);
  * pcr_ctx_read_kernel_times synchronises, returns per class the summed kernel time in ms and the
  * number of launches since the previous read, and resets the counters.
  * class 0: source transform, 1: fused ICP step, 2: partial fold, 3: K-NN query.
- * on: 0 = off, 1 = every class, otherwise (mask << 1) with bit c of mask selecting class c (an event pair costs
- * a few microseconds of queue time per launch: a timed loop brackets only the kernel it reports). */
+ * on: 0 = off, 1 = every class, otherwise (mask << 1) | (stride << 8) with bit c of mask selecting class c and, for
+ * stride > 1, only every stride-th launch of a class bracketed, the first included (an event pair costs microseconds of
+ * queue time per launch -- 7 us of a 153 us iteration when every launch is bracketed: a timed loop brackets only the
+ * kernel it reports, and only a sample of its launches). */
 int pcr_ctx_set_profiling(pcr_ctx *ctx, int on);
 int pcr_ctx_read_kernel_times(pcr_ctx *ctx, double sum_ms[4], uint32_t launches[4]);
+/* the bracketed launches of one class one by one, in launch order (ms); synchronises, resets nothing; *count = how
+ * many there are (the first min(cap, *count) are written) */
+int pcr_ctx_read_kernel_launches(pcr_ctx *ctx, int kernel_class, double *ms_out, uint32_t cap, uint32_t *count);
 
 /* ---- clouds ------------------------------------------------------------------------
  * Replaces the borrowed `const double*` of hiveCommon::CKNNSearch::initKNNSearch
@@ -307,6 +312,10 @@ int pcr_fit_enqueue_solve(pcr_fit *fit);
 /* pcr_fit_enqueue_step + pcr_fit_enqueue_solve for a fit that needs no exchange in between (one GPU): where the step
  * runs as the filtered kernel, its last block folds the partials and runs the solve -- ONE launch per iteration. */
 int pcr_fit_enqueue_iteration(pcr_fit *fit);
+/* `count` of those as ONE HIP graph launch: captured on the first call with that count (no kernel argument depends on
+ * the iteration), replayed afterwards; falls back to `count` plain launches while kernel timing is on.  Surplus
+ * iterations after convergence are no-ops, as always. */
+int pcr_fit_enqueue_iterations(pcr_fit *fit, uint32_t count);
 /* ---- many small fits, ONE launch per iteration ---------------------------------------------------
  * The caller of the loop (CRegistartion::fineFit per scan pair, Registration.cpp:148-158; unit test/FineRegistration/
  * TestFineRegistration.cpp:26-92) registers a scan set pair by pair: independent problems, each too small to fill

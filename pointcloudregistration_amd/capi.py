@@ -86,7 +86,9 @@ SYMBOLS = {
     "pcr_fit_enqueue_step": (C.c_int, [_vp]),
     "pcr_fit_partials_d": (_vp, [_vp]),
     "pcr_fit_enqueue_solve": (C.c_int, [_vp]),
+    "pcr_ctx_read_kernel_launches": (C.c_int, [_vp, C.c_int, _dp, C.c_uint32, _up]),
     "pcr_fit_enqueue_iteration": (C.c_int, [_vp]),
+    "pcr_fit_enqueue_iterations": (C.c_int, [_vp, C.c_uint32]),
     "pcr_fit_batch_create": (C.c_int, [_vp, C.POINTER(_vp), C.c_uint32, C.POINTER(_vp)]),
     "pcr_fit_batch_enqueue_iteration": (C.c_int, [_vp]),
     "pcr_fit_batch_destroy": (C.c_int, [_vp]),
@@ -169,9 +171,11 @@ class Context:
         if stream is not None:
             _check(lib().pcr_ctx_set_stream(self.h, _vp(stream.cuda_stream)), "pcr_ctx_set_stream")
 
-    def set_profiling(self, on, classes=None):
-        """classes: iterable of kernel classes (0 transform, 1 step, 2 fold, 3 knn) to bracket; None = all."""
-        v = 0 if not on else (1 if classes is None else sum(1 << c for c in classes) << 1)
+    def set_profiling(self, on, classes=None, stride=1):
+        """classes: iterable of kernel classes (0 transform, 1 step, 2 fold, 3 knn) to bracket; None = all.
+        stride > 1: only every stride-th launch of a class is bracketed (the first one included)."""
+        mask = 0xf if classes is None else sum(1 << c for c in classes)
+        v = 0 if not on else (1 if classes is None and stride <= 1 else (mask << 1) | ((stride & 0xff) << 8))
         _check(lib().pcr_ctx_set_profiling(self.h, v), "pcr_ctx_set_profiling")
 
     def read_kernel_times(self):
@@ -180,6 +184,13 @@ class Context:
         cnt = np.zeros(4, np.uint32)
         _check(lib().pcr_ctx_read_kernel_times(self.h, _d(ms), _u(cnt)), "pcr_ctx_read_kernel_times")
         return {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(("transform", "step", "fold", "knn"))}
+
+    def read_kernel_launches(self, cls):
+        """ms of every bracketed launch of one class since the previous read_kernel_times, in launch order."""
+        ms = np.zeros(1024)
+        cnt = C.c_uint32(0)
+        _check(lib().pcr_ctx_read_kernel_launches(self.h, cls, _d(ms), 1024, C.byref(cnt)), "pcr_ctx_read_kernel_launches")
+        return ms[:min(cnt.value, 1024)].copy()
 
     def synchronize(self):
         _check(lib().pcr_ctx_synchronize(self.h), "pcr_ctx_synchronize")
@@ -427,6 +438,10 @@ class Fit:
     def iterate(self):
         """step + solve with nothing in between: one launch per iteration where the filtered kernel applies."""
         _check(lib().pcr_fit_enqueue_iteration(self.h), "pcr_fit_enqueue_iteration")
+
+    def iterate_many(self, count):
+        """`count` iterations as one HIP graph launch (captured on first use with that count)."""
+        _check(lib().pcr_fit_enqueue_iterations(self.h, count), "pcr_fit_enqueue_iterations")
 
     def partials_tensor(self):
         """The 17 partial sums as a torch view of the fit's device buffer (for torch.distributed.all_reduce)."""

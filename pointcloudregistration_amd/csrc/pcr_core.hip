@@ -752,6 +752,8 @@ int pcr_ctx_set_profiling(pcr_ctx *c, int on) {
     }
     c->profiling = on != 0;
     c->prof_mask = on == 1 ? 0xfu : ((unsigned)on >> 1) & 0xfu;
+    c->prof_stride = on == 1 ? 1u : ((unsigned)on >> 8) & 0xffu;
+    for (int k = 0; k < PCR_PROF_CLASSES; ++k) c->prof_seq[k] = 0;
     return PCR_OK;
 }
 
@@ -773,6 +775,23 @@ int pcr_ctx_read_kernel_times(pcr_ctx *c, double sum_ms[4], uint32_t launches[4]
         launches[k] = (uint32_t)c->prof->used[k];
         c->prof->used[k] = 0;
     }
+    return PCR_OK;
+}
+
+int pcr_ctx_read_kernel_launches(pcr_ctx *c, int cls, double *ms_out, uint32_t cap, uint32_t *count) {
+    PCR_REQUIRE(c && count && (ms_out || cap == 0), "pcr_ctx_read_kernel_launches: NULL argument");
+    PCR_REQUIRE(cls >= 0 && cls < PCR_PROF_CLASSES, "pcr_ctx_read_kernel_launches: class %d", cls);
+    *count = 0;
+    if (!c->prof) return PCR_OK;
+    PCR_HIP(hipSetDevice(c->device));
+    PCR_HIP(hipStreamSynchronize(c->stream));
+    const int n = c->prof->used[cls];
+    for (int i = 0; i < n && (uint32_t)i < cap; ++i) {
+        float ms = 0;
+        PCR_HIP(hipEventElapsedTime(&ms, c->prof->start[cls][i], c->prof->stop[cls][i]));
+        ms_out[i] = ms;
+    }
+    *count = (uint32_t)n;
     return PCR_OK;
 }
 

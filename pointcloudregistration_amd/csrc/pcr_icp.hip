@@ -915,7 +915,14 @@ struct pcr_fit {
     uint32_t *tickets_d;
     float *dk_d;          // [m] StepArgs::dk_io
     FitDev init;          // host-side template of the state (reset copies it)
+    hipGraphExec_t graph_exec;  // pcr_fit_enqueue_iterations: `graph_count` iterations captured once, replayed
+    uint32_t graph_count;
 };
+static void fit_drop_graph(pcr_fit *f) {
+    if (f->graph_exec) hipGraphExecDestroy(f->graph_exec);
+    f->graph_exec = nullptr;
+    f->graph_count = 0;
+}
 
 // (re)allocates the in-kernel fold's scratch for f->nb blocks; tickets start at zero and every launch leaves them so
 static hipError_t fit_alloc_fold(pcr_fit *f) {
@@ -1318,6 +1325,7 @@ int pcr_fit_destroy(pcr_fit *f) {
     if (!f) return PCR_OK;
     hipSetDevice(f->ctx->device);
     hipStreamSynchronize(f->ctx->stream);
+    fit_drop_graph(f);
     if (f->dev_d) hipFree(f->dev_d);
     if (f->dev_h) hipHostFree(f->dev_h);
     if (f->partials_d) hipFree(f->partials_d);
@@ -1401,6 +1409,7 @@ int pcr_fit_set_samples(pcr_fit *f, const uint32_t *sample_idx, uint32_t m) {
         PCR_REQUIRE(sample_idx[i] < f->src->n, "pcr_fit_set_samples: sample_idx[%u]=%u out of range", i, sample_idx[i]);
     PCR_HIP(hipSetDevice(f->ctx->device));
     PCR_HIP(hipStreamSynchronize(f->ctx->stream));  // nothing in flight may still read the old list or partials
+    fit_drop_graph(f);                              // (a captured launch holds the old grid size)
     if (f->samples_d) hipFree(f->samples_d);
     f->samples_d = nullptr;
     const uint32_t nb = m ? (m + 255) / 256 : 0;
@@ -1553,6 +1562,44 @@ int pcr_fit_enqueue_iteration(pcr_fit *f) {
         hipLaunchKernelGGL(fit_solve_kernel, dim3(1), dim3(64), 0, f->ctx->stream, f->dev_d, (const double *)f->partials_d,
                            f->traj_d);
     PCR_HIP(hipGetLastError());
+    return PCR_OK;
+}
+
+int pcr_fit_enqueue_iterations(pcr_fit *f, uint32_t count) {
+    PCR_REQUIRE(f, "pcr_fit_enqueue_iterations: NULL argument");
+    if (count == 0) return PCR_OK;
+    PCR_HIP(hipSetDevice(f->ctx->device));
+    // (event brackets are per launch: no graph while kernels are being timed; the legacy default stream cannot capture)
+    if (count == 1 || f->ctx->profiling || f->ctx->stream == nullptr) {
+        for (uint32_t i = 0; i < count; ++i) {
+            const int rc = pcr_fit_enqueue_iteration(f);
+            if (rc != PCR_OK) return rc;
+        }
+        return PCR_OK;
+    }
+    if (!f->graph_exec || f->graph_count != count) {
+        // capture `count` iterations once: no kernel argument depends on the iteration (the state lives in device
+        // memory), so the same graph serves every later call with this count
+        fit_drop_graph(f);
+        hipGraph_t graph = nullptr;
+        PCR_HIP(hipStreamBeginCapture(f->ctx->stream, hipStreamCaptureModeThreadLocal));
+        int rc = PCR_OK;
+        for (uint32_t i = 0; i < count && rc == PCR_OK; ++i) rc = pcr_fit_enqueue_iteration(f);
+        const hipError_t e = hipStreamEndCapture(f->ctx->stream, &graph);
+        if (rc != PCR_OK || e != hipSuccess || !graph) {
+            if (graph) hipGraphDestroy(graph);
+            if (rc != PCR_OK) return rc;
+            PCR_HIP(e != hipSuccess ? e : hipErrorUnknown);
+        }
+        const hipError_t ei = hipGraphInstantiate(&f->graph_exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (ei != hipSuccess) {
+            f->graph_exec = nullptr;
+            PCR_HIP(ei);
+        }
+        f->graph_count = count;
+    }
+    PCR_HIP(hipGraphLaunch(f->graph_exec, f->ctx->stream));
     return PCR_OK;
 }
 

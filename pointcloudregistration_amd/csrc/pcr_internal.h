@@ -99,6 +99,8 @@ struct pcr_ctx {
     int device;
     bool profiling;
     unsigned prof_mask;  // bit c: launches of kernel class c are bracketed while profiling is on
+    unsigned prof_stride;                  // every prof_stride-th launch of a class is bracketed (0, 1: every launch)
+    unsigned prof_seq[4];                  // launches seen per class since profiling was switched on
     pcr_prof *prof;
     hipStream_t stream;
     bool own_stream;
@@ -121,6 +123,7 @@ struct ProfScope {
     int cls, slot;
     ProfScope(pcr_ctx *ctx, int k) : c(ctx), cls(k), slot(-1) {
         if (!c->profiling || !c->prof || !((c->prof_mask >> cls) & 1u)) return;
+        if (c->prof_stride > 1 && (c->prof_seq[cls]++ % c->prof_stride) != 0) return;
         pcr_prof &p = *c->prof;
         if (p.used[cls] >= PCR_PROF_CAP) return;
         if (p.used[cls] >= p.created[cls]) {

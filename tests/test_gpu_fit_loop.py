@@ -141,3 +141,27 @@ def test_concurrent_fits_on_two_contexts_share_one_pair_of_indices(pcr, ctx):
     for f in fits:
         f.close()
     other.close()
+
+
+def test_graph_replay_of_many_iterations_equals_plain_launches(pcr, ctx):
+    """pcr_fit_enqueue_iterations: N iterations captured once as a HIP graph and replayed -- the whole trajectory must
+    equal N single launches bit for bit, on the first (capturing) call, on a replay, with a different count (recapture),
+    with criteria on (surplus iterations are no-ops), and with kernel timing on (falls back to plain launches)."""
+    g = golden("spheres40k_k4.npz")
+    src, tgt = case_inputs("spheres40k_k4", g)
+    six, tix = pcr.Index(ctx, pcr.Cloud(ctx, src), kind=pcr.INDEX_GRID), pcr.Index(ctx, pcr.Cloud(ctx, tgt), kind=pcr.INDEX_GRID)
+    U = tix.unique_sq_dist()
+    for conv in (None, pcr.ConvergenceParams.regcfg(30)):
+        fit = pcr.Fit(ctx, six, tix, 4, U * 36, U * 4, conv=conv, unique_sq_dist=U, traj_cap=16)
+        want = fit.run(g["R0"], g["T0"], 12)
+        for count, timing in ((12, False), (12, False), (7, False), (12, True)):
+            fit.reset(g["R0"], g["T0"])
+            ctx.set_profiling(timing)
+            fit.iterate_many(count)
+            if count < 12:
+                fit.iterate_many(12 - count)
+            ctx.set_profiling(False)
+            got = fit.read()
+            assert got["iterations"] == want["iterations"] and got["state"] == want["state"]
+            assert (got["traj"] == want["traj"]).all() and (got["R"] == want["R"]).all() and (got["T"] == want["T"]).all()
+        fit.close()
