@@ -208,7 +208,11 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
             const uint32_t rowk = sat_add(DY[r] < 0 ? gyl_k : (DY[r] > 0 ? gyh_k : 0u), DZ[r] < 0 ? gzl_k : (DZ[r] > 0 ? gzh_k : 0u));
             const bool inside = (DY[r] < 0 ? y_lo : (DY[r] > 0 ? y_hi : true)) & (DZ[r] < 0 ? z_lo : (DZ[r] > 0 ? z_hi : true));
             const bool open = inside & !(rowk > UB0);
-            const uint32_t p0 = has_xl ? b[r].x : b[r].y, p1 = b[r].y, p2 = b[r].z, p3 = has_xh ? b[r].w : b[r].z;
+            // (the first element goes through an opaque copy: the compiler otherwise turns `has_xl ? b.x : b.y` into a
+            // run-time vector index and lowers THAT as a chain of three compare-and-selects over all four elements)
+            uint32_t bx = b[r].x;
+            asm volatile("" : "+v"(bx));
+            const uint32_t p0 = has_xl ? bx : b[r].y, p1 = b[r].y, p2 = b[r].z, p3 = has_xh ? b[r].w : b[r].z;
             const uint32_t tot = p3 - p0;
             ok &= !(open & (tot > 255u));  // the payload holds 8 bits of offset: a longer row is the fp64 walk's business
             if (open & (tot != 0u)) {
@@ -307,8 +311,27 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
         ed[0] = seed_d;
         ei[0] = seed_i;
     }
+    {
+        // all KC gathers in flight together: positions first (LDS), then the 32-byte records (an empty list slot reads
+        // record 0 and is masked), then the arithmetic -- not KC dependent round trips one after the other
+        uint32_t cpos[KC];
 #pragma unroll
-    for (int j = 0; j < KC; ++j) evaluate(T.t[j], ed[NS + j], ei[NS + j]);
+        for (int j = 0; j < KC; ++j) {
+            const uint32_t key = T.t[j];
+            const uint32_t base = rowtab[((key >> 8) & 15u) * PCR_ROW_STRIDE].x;
+            cpos[j] = key != KEY_SENTINEL ? base + (key & 255u) : 0u;
+        }
+        Pt4 crec[KC];
+#pragma unroll
+        for (int j = 0; j < KC; ++j) crec[j] = exact_pts[cpos[j]];
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            const double dd = cand_d2<XF, RG>(xf, qx, qy, qz, crec[j]);
+            const bool in = (T.t[j] != KEY_SENTINEL) & (dd < max_d2);
+            ed[NS + j] = in ? dd : max_d2;
+            ei[NS + j] = in ? (uint32_t)crec[j].w : PCR_NO_INDEX;
+        }
+    }
     double ek;
     uint32_t ik;
     ranks_of<KC + NS>(ed, ei, rk);
