@@ -115,6 +115,16 @@ struct FastExact {
     int n;
 };
 
+// timing build only (PCR_BLOCK_TIMES): the shader clock at stage boundaries of one search, kept in scalar registers
+struct StageClock {
+    uint32_t t[4];
+};
+#ifdef PCR_BLOCK_TIMES
+#define STAGE_CLOCK(clk, i) do { if (clk) (clk)->t[i] = (uint32_t)__builtin_readcyclecounter(); } while (0)
+#else
+#define STAGE_CLOCK(clk, i) do { } while (0)
+#endif
+
 // One lane, one query, the 3x3x3 cells around it.
 //   g          a single-level grid WITH shadows (g.shadow != NULL)
 //   exact_pts  the fp64 records the distances that decide are evaluated against (g.pts)
@@ -129,6 +139,11 @@ struct FastExact {
 //              search of the ICP step: the sample's own image); it takes part in the ranking
 //   out_d/out_i  on return true: the k-th smallest (d2, index) exactly -- (max_d2, PCR_NO_INDEX) if fewer than k
 //              candidates lie below max_d2
+//   win_pos    (optional) the same as a position in exact_pts (PCR_NO_INDEX: not listed) -- four registers where `win`
+//              holds 8 * KC over the ranking; one round trip saved instead of two
+//   win        (optional) receives the fp64 record of the point behind out_i when that point was one of the listed
+//              candidates (w = its index; zeros otherwise, e.g. when the seed itself wins and was not listed): the
+//              caller then need not gather it again -- two dependent round trips saved per search
 // Returns false when this search cannot vouch for the result (not settled within ring 1, a cell row too long for the
 // payload, a query far outside the grid, an unresolved near-tie): the caller runs lane_search instead.
 // TRIES: see phase 2.  GV, RG: GridView and Rigid in whatever address space the caller keeps them (the step kernel: the constant one,
@@ -138,7 +153,8 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
                                            double qz, double sx, double sy, double sz, double max_d2, double bound_d2,
                                            double bound_scale, double extra_margin, uint32_t delta, int k,
                                            double seed_d, uint32_t seed_i, double &out_d, uint32_t &out_i,
-                                           uint2 *rowtab, const RG *xf, FastExact<KC> *all = nullptr) {
+                                           uint2 *rowtab, const RG *xf, FastExact<KC> *all = nullptr,
+                                           StageClock *clk = nullptr, Pt4 *win = nullptr, uint32_t *win_pos = nullptr) {
     constexpr int KP = KC + 2;
     constexpr int U = PCR_FAST_U;
     const uint32_t *__restrict__ cs = g.cs;
@@ -191,6 +207,7 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
     const uint32_t cells = (uint32_t)gx * (uint32_t)gy * (uint32_t)gz;
     const __amdgpu_buffer_rsrc_t rs_cs = __builtin_amdgcn_make_buffer_rsrc((void *)(cs - 1), 0, (int)((cells + 3u) * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_sh = __builtin_amdgcn_make_buffer_rsrc((void *)shadow, 0, (int)(g.n * 16u), 0x00020000);
+    STAGE_CLOCK(clk, 0);
     uint32_t cnt = 0;
     {
         constexpr int DY[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
@@ -225,6 +242,7 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
     // row and, when that does not fill it, opens the next row and continues there -- a lane's trips are about
     // (candidates + pruned rows) / U, not one or more per row.  Slot u of a trip reads position (u < rem ? p : p2 - rem)
     // + u: an unused slot may read anything (or, past the end of the array, nothing): its key is the sentinel.
+    STAGE_CLOCK(clk, 1);
     TopKeys<KP> T;
     T.init();
     uint32_t p = 0, e = 0, pb = 0, ri = 0;
@@ -284,11 +302,14 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
         }
         alive = (p < e) | (ri < cnt);
     }
+    STAGE_CLOCK(clk, 2);
     // ---- phase 3: fp64 decides.  The candidates behind the KC smallest keys, exactly; the k-th of them by ranking
     // (every pair compared once); then the verification.
     constexpr int NS = SEEDED ? 1 : 0;
     double ed[KC + 1 + NS];
     uint32_t ei[KC + 1 + NS], rk[KC + 1 + NS];
+    Pt4 rec2 = {0.0, 0.0, 0.0, 0ull};  // the second stage's record, if one is read
+    uint32_t pos2 = 0u;
     auto evaluate = [&](uint32_t key, double &d, uint32_t &ci) {
         d = max_d2;
         ci = PCR_NO_INDEX;
@@ -299,6 +320,8 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
             if (dd < max_d2) {
                 d = dd;
                 ci = (uint32_t)cnd.w;
+                rec2 = cnd;
+                pos2 = pos;
             }
         }
     };
@@ -311,17 +334,17 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
         ed[0] = seed_d;
         ei[0] = seed_i;
     }
+    Pt4 crec[KC];
+    uint32_t cpos[KC];
     {
         // all KC gathers in flight together: positions first (LDS), then the 32-byte records (an empty list slot reads
         // record 0 and is masked), then the arithmetic -- not KC dependent round trips one after the other
-        uint32_t cpos[KC];
 #pragma unroll
         for (int j = 0; j < KC; ++j) {
             const uint32_t key = T.t[j];
             const uint32_t base = rowtab[((key >> 8) & 15u) * PCR_ROW_STRIDE].x;
             cpos[j] = key != KEY_SENTINEL ? base + (key & 255u) : 0u;
         }
-        Pt4 crec[KC];
 #pragma unroll
         for (int j = 0; j < KC; ++j) crec[j] = exact_pts[cpos[j]];
 #pragma unroll
@@ -332,6 +355,7 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
             ei[NS + j] = in ? (uint32_t)crec[j].w : PCR_NO_INDEX;
         }
     }
+    ei[KC + NS] = PCR_NO_INDEX;
     double ek;
     uint32_t ik;
     ranks_of<KC + NS>(ed, ei, rk);
@@ -367,6 +391,33 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
         }
         all->n = n_exact;
     }
+    if (win_pos) {
+        uint32_t wp = PCR_NO_INDEX;
+        const bool any = ik != PCR_NO_INDEX;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) wp = (any & (ei[NS + j] == ik)) ? cpos[j] : wp;
+        wp = (any & (ei[KC + NS] == ik)) ? pos2 : wp;
+        *win_pos = wp;
+    }
+    if (win) {  // the record behind the winning index, picked by index (every listed candidate is a different point)
+        Pt4 w = {0.0, 0.0, 0.0, 0ull};
+        const bool any = ik != PCR_NO_INDEX;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            const bool sel = any & (ei[NS + j] == ik);
+            w.x = sel ? crec[j].x : w.x;
+            w.y = sel ? crec[j].y : w.y;
+            w.z = sel ? crec[j].z : w.z;
+            w.w = sel ? crec[j].w : w.w;
+        }
+        const bool sel2 = any & (ei[KC + NS] == ik);
+        w.x = sel2 ? rec2.x : w.x;
+        w.y = sel2 ? rec2.y : w.y;
+        w.z = sel2 ? rec2.z : w.z;
+        w.w = sel2 ? rec2.w : w.w;
+        *win = w;
+    }
+    STAGE_CLOCK(clk, 3);
     const bool settled = (ek < settle_b2) | (max_d2 <= settle_b2);
     DIAG_LANE_ADD(19 + 4 * XF, (ok & verified & settled) ? 0 : 1);  // handed to the fp64 walk
     out_d = ek;

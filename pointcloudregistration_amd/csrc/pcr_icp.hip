@@ -265,6 +265,11 @@ __device__ __forceinline__ void fold_in_kernel(AP A, uint32_t lb, uint32_t nb) {
 #ifdef PCR_BLOCK_TIMES
 // timing build only (never shipped): start/end of every block of the last grid-kernel launch, 100 MHz ticks
 __device__ unsigned long long g_block_times[2 * 65536];
+__device__ unsigned long long g_fast_times[4 * 65536];  // filtered kernel: start, forward search done, reverse done, end
+__device__ uint32_t g_fast_clocks[16 * 65536];          // ... and wave 0's shader clock at 14 stage boundaries
+#define FAST_STAMP(i) do { if (threadIdx.x == 0 && lb < 65536u) g_fast_times[4 * lb + (i)] = wall_clock64(); } while (0)
+#else
+#define FAST_STAMP(i) do { } while (0)
 #endif
 template <int KC, bool MULTI>
 __global__ void __launch_bounds__(256, MULTI ? PCR_MULTI_WAVES : PCR_STEP_WAVES) icp_step_grid_kernel(StepArgs A) {
@@ -495,26 +500,38 @@ __device__ PCR_FALLBACK_INLINE uint32_t fallback_reverse(const StepArgs *__restr
 template <int KC>
 __device__ __forceinline__ void fast_step_body(const StepArgs *__restrict__ Ap, uint32_t lb, uint32_t nb) {
     if (Ap->dyn->done) return;  // uniform over the problem's blocks
+    FAST_STAMP(0);
+#ifdef PCR_BLOCK_TIMES
+    uint32_t ck[6];
+    StageClock ckf, ckr;
+    for (int i = 0; i < 4; ++i) ckf.t[i] = ckr.t[i] = 0;
+    StageClock *pf = &ckf, *pr = &ckr;
+    ck[0] = (uint32_t)__builtin_readcyclecounter();
+#else
+    StageClock *pf = nullptr, *pr = nullptr;
+#endif
     const uint32_t t = lb * 256u + threadIdx.x;
     __shared__ __align__(16) unsigned char smem[REDUCE17_LDS_BYTES];  // row tables, then the block reduction's scratch
     uint2 *my_rows = (uint2 *)smem + threadIdx.x;
     uint32_t pos = 0, orig = 0, slot = 0;
     double px = 0, py = 0, pz = 0;
+    float dk_prev = __builtin_huge_valf();  // last iteration's K-th squared distance (loaded beside the point: one wait)
     bool live;
     {
         const PCR_CONST_AS StepArgs *A = reload_from(Ap);
         live = t < A->m;
         if (live) {
-            if (A->sample_idx) {
+            const bool listed = A->sample_idx != nullptr;
+            if (listed) {
                 orig = A->sample_idx[t];
                 pos = A->src_pos_of[orig];
-                slot = t;
             } else {
                 pos = A->src_order[A->sample_begin + t];
-                orig = (uint32_t)A->src.all[pos].w;
-                slot = orig;
             }
-            const Pt4 s = A->src.all[pos];
+            if (A->dk_io) dk_prev = A->dk_io[t];
+            const Pt4 s = A->src.all[pos];  // one read of the record: the original index rides in .w
+            if (!listed) orig = (uint32_t)s.w;
+            slot = listed ? t : orig;
             xform(reload_from(A->dyn)->M, s.x, s.y, s.z, px, py, pz);  // CurSrcPoint = R*s + T (:86)
         }
     }
@@ -522,7 +539,8 @@ __device__ __forceinline__ void fast_step_body(const StepArgs *__restrict__ Ap, 
     const bool fin = live && isfinite(px) && isfinite(py) && isfinite(pz);
     double dF;
     uint32_t j;
-    bool found, passF, need_rev;
+    bool found, passF, need_rev, q_known;
+    uint32_t qpos = PCR_NO_INDEX;
     {
         const PCR_CONST_AS StepArgs *A = reload_from(Ap);
         const PCR_CONST_AS GridView &GT = A->tgt.v[0];
@@ -535,13 +553,15 @@ __device__ __forceinline__ void fast_step_body(const StepArgs *__restrict__ Ap, 
         double bound_d2 = PCR_INF;
         float *dk_io = A->dk_io;
         if (dk_io && live) {
-            const float a = sqrtf(dk_io[t]) * 1.0000005f, b = reload_from(A->dyn)->disp_bound;
+            const float a = sqrtf(dk_prev) * 1.0000005f, b = reload_from(A->dyn)->disp_bound;
             const float s2 = (a + b) * 1.0000005f;
             bound_d2 = (double)(s2 * s2) * 1.000001;  // inf stays inf
         }
         if (fin)  // NeighborSet.back() = K-th nearest (:91-92)
             fwd_done = fast_ring1<KC, false, false>(GT, GT.pts, px, py, pz, px, py, pz, fmax_d2, bound_d2, fwd_scale, 0.0,
-                                                    GT.key_delta, A->k, 0.0, 0u, dF, j, my_rows, (const Rigid *)nullptr);
+                                                    GT.key_delta, A->k, 0.0, 0u, dF, j, my_rows, (const Rigid *)nullptr, nullptr, pf,
+                                                    nullptr, &qpos);
+        q_known = fin & fwd_done & (qpos != PCR_NO_INDEX);  // the walk hands over q's position with its index
         if (__any(!fwd_done)) {
             if (!fwd_done) fallback_forward<KC>(Ap, px, py, pz, fmax_d2, fwd_scale, A->k, my_rows, &dF, &j);
         }
@@ -550,6 +570,10 @@ __device__ __forceinline__ void fast_step_body(const StepArgs *__restrict__ Ap, 
         need_rev = found && (passF || A->exact);
         if (dk_io && live) dk_io[t] = found ? __double2float_ru(dF) : __builtin_huge_valf();
     }
+    FAST_STAMP(1);
+#ifdef PCR_BLOCK_TIMES
+    ck[1] = (uint32_t)__builtin_readcyclecounter();
+#endif
     // ---- reverse: nearest TRANSFORMED source point of q (:94-95), seeded with the sample's own image (distance dF)
     double qx = 0, qy = 0, qz = 0;
     uint32_t r = PCR_NO_INDEX;
@@ -560,7 +584,8 @@ __device__ __forceinline__ void fast_step_body(const StepArgs *__restrict__ Ap, 
         const PCR_CONST_AS GridView &GS = A->src.v[0];
         double sx = 0, sy = 0, sz = 0;
         if (need_rev) {
-            const Pt4 qpt = A->tgt.all[A->tgt.pos_of[j]];
+            if (!q_known) qpos = A->tgt.pos_of[j];  // (the fp64 walk returns the index only)
+            const Pt4 qpt = A->tgt.all[qpos];
             qx = qpt.x;
             qy = qpt.y;
             qz = qpt.z;
@@ -579,19 +604,27 @@ __device__ __forceinline__ void fast_step_body(const StepArgs *__restrict__ Ap, 
         bool rev_done = !rev_active;
         double dRv = dF;  // the reverse winner's distance to q (not used further) and index
         uint32_t rv = orig;
+        Pt4 srec = {0.0, 0.0, 0.0, 0ull};
         if (rev_active)
             rev_done = fast_ring1<1, true, true>(GS, GS.pts, qx, qy, qz, sx, sy, sz, PCR_INF, dF, rbs, rem_, rev_delta, 1, dF,
-                                                 orig, dRv, rv, my_rows, &D->M);
+                                                 orig, dRv, rv, my_rows, &D->M, nullptr, pr, &srec);
+        const bool s_known = rev_active & rev_done;
         if (__any(!rev_done)) {
             if (!rev_done) rv = fallback_reverse(Ap, qx, qy, qz, sx, sy, sz, rbs, rem_, dF, orig, my_rows);
         }
         if (need_rev) {
             r = rv;
-            const Pt4 sp = A->src.all[r == orig ? pos : A->src_pos_of[r]];
-            const double dR = cand_d2<true>(&D->M, px, py, pz, sp);  // (CurSrcPoint - TmpPoint).squaredNorm()
-            keep = passF && dR < A->thr_rev;                          // strict < (:98)
+            // (CurSrcPoint - TmpPoint).squaredNorm(): TmpPoint is the sample's own image when r is the sample -- the same
+            // expression on the same operands as p, so the difference is exactly zero -- else the walk's winning record
+            if (!s_known && r != orig) srec = A->src.all[A->src_pos_of[r]];
+            const double dR = r == orig ? 0.0 : cand_d2<true>(&D->M, px, py, pz, srec);
+            keep = passF && dR < A->thr_rev;  // strict < (:98)
         }
     }
+    FAST_STAMP(2);
+#ifdef PCR_BLOCK_TIMES
+    ck[2] = (uint32_t)__builtin_readcyclecounter();
+#endif
     const PCR_CONST_AS StepArgs *A = reload_from(Ap);
     double acc[17];
 #pragma unroll
@@ -603,6 +636,14 @@ __device__ __forceinline__ void fast_step_body(const StepArgs *__restrict__ Ap, 
         if (A->out_keep) A->out_keep[slot] = keep ? 1 : 0;
     }
     block_reduce17(acc, (double *)smem, A->block_partials, lb, nb);
+    FAST_STAMP(3);
+#ifdef PCR_BLOCK_TIMES
+    ck[3] = (uint32_t)__builtin_readcyclecounter();
+    if (threadIdx.x == 0 && lb < 65536u) {
+        uint32_t *o = g_fast_clocks + 16 * (size_t)lb;
+        for (int i = 0; i < 4; ++i) { o[i] = ck[i]; o[4 + i] = ckf.t[i]; o[8 + i] = ckr.t[i]; }
+    }
+#endif
     fold_in_kernel(A, lb, nb);
 }
 
@@ -1638,6 +1679,12 @@ int pcr_fit_read(pcr_fit *f, double R[9], double T[3], uint32_t *iterations, int
 }  // extern "C"
 
 #ifdef PCR_BLOCK_TIMES
+extern "C" int pcr_diag_fast_clocks(unsigned *out, unsigned n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pcr::g_fast_clocks), sizeof(unsigned) * 16 * n) == hipSuccess ? 0 : -2;
+}
+extern "C" int pcr_diag_fast_times(unsigned long long *out, unsigned n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pcr::g_fast_times), sizeof(unsigned long long) * 4 * n) == hipSuccess ? 0 : -2;
+}
 extern "C" int pcr_diag_block_times(unsigned long long *out, unsigned n) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(pcr::g_block_times), sizeof(unsigned long long) * 2 * n) == hipSuccess ? 0 : -2;
 }
