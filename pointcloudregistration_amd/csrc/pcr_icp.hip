@@ -222,6 +222,9 @@ __device__ __forceinline__ void fold17(const double *x, size_t stride, uint32_t 
     if (tid < 136u && sub == 0u) st_agent(&out[(size_t)col * out_stride], s);
 }
 
+#ifdef PCR_BLOCK_TIMES
+__device__ unsigned long long g_solve_times[4];  // timing build: last fold's start, solve start, solve end (100 MHz ticks)
+#endif
 // After block_reduce17: the in-kernel fold described at StepArgs::tickets.  Block-uniform control flow throughout.
 template <class AP>
 __device__ __forceinline__ void fold_in_kernel(AP A, uint32_t lb, uint32_t nb) {
@@ -246,13 +249,22 @@ __device__ __forceinline__ void fold_in_kernel(AP A, uint32_t lb, uint32_t nb) {
         s_last = __hip_atomic_fetch_add(&tickets[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1u ? 1u : 0u;
     __syncthreads();
     if (!s_last) return;
+#ifdef PCR_BLOCK_TIMES
+    if (threadIdx.x == 0) g_solve_times[0] = wall_clock64();
+#endif
     double *out = A->partials_out;
     fold17(A->group_partials, ngroups, ngroups, out, 1);
     for (uint32_t i = threadIdx.x; i < ngroups + 1u; i += 256u) tickets[i] = 0u;
     FitDev *fit = A->fit_inline;
     if (fit) {
         __syncthreads();
+#ifdef PCR_BLOCK_TIMES
+        if (threadIdx.x == 0) g_solve_times[1] = wall_clock64();
+#endif
         if (threadIdx.x == 0) fit_solve_body(fit, out, A->fit_traj);
+#ifdef PCR_BLOCK_TIMES
+        if (threadIdx.x == 0) g_solve_times[2] = wall_clock64();
+#endif
     }
 }
 
@@ -828,12 +840,12 @@ __global__ void fit_init_kernel(FitDev value, FitDev *dst) { *dst = value; }
 // computeRotationAndTranslation, then the convergence criteria -- followed by the preparation of the next step.
 __device__ __noinline__ void fit_solve_body(FitDev *__restrict__ F, const double *__restrict__ partials,
                                             double *__restrict__ traj) {
-    if (F->dyn.done) return;
+    // one thread, and every load from device memory costs it a microsecond: fetch the sums and the whole state at once
+    // (all loads in flight together, the `done` flag among them) and read the copy from here on; stores go to *F
     double part[17];
     for (int i = 0; i < 17; ++i) part[i] = partials[i];
-    // one thread, and every load from device memory costs it a microsecond: fetch the whole state at once (all loads in
-    // flight together) and read the copy from here on; stores go to *F
     const FitDev f = *F;
+    if (f.dyn.done) return;
     const uint32_t it = f.iteration + 1;  // the reference counts from 1 (IterativeFit.cpp:121-123)
     F->iteration = it;
     F->last_n = part[0];
@@ -1679,6 +1691,9 @@ int pcr_fit_read(pcr_fit *f, double R[9], double T[3], uint32_t *iterations, int
 }  // extern "C"
 
 #ifdef PCR_BLOCK_TIMES
+extern "C" int pcr_diag_solve_times(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pcr::g_solve_times), sizeof(unsigned long long) * 4) == hipSuccess ? 0 : -2;
+}
 extern "C" int pcr_diag_fast_clocks(unsigned *out, unsigned n) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(pcr::g_fast_clocks), sizeof(unsigned) * 16 * n) == hipSuccess ? 0 : -2;
 }

@@ -49,9 +49,14 @@ PCR_HD inline bool jacobi_pair(double *A, double *V) {
         beta += A[J * 3 + r] * A[J * 3 + r];
         gamma += A[I * 3 + r] * A[J * 3 + r];
     }
-    if (fabs(gamma) <= 4.440892098500626e-16 * sqrt(alpha * beta)) return false;
-    const double zeta = (beta - alpha) / (2.0 * gamma);
-    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    // (one thread runs this, and on the device every fp64 square root or division is a dependent chain of a dozen
+    // instructions: the test is taken on squares, and t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)) with
+    // zeta = (beta - alpha) / (2 gamma) is evaluated with numerator and denominator multiplied by 2 |gamma| -- two square
+    // roots and two divisions per rotation where the textbook form has three of each)
+    const double g2 = gamma * gamma;
+    if (g2 <= 1.9721522630525295e-31 * (alpha * beta)) return false;  // |gamma| <= 2^-51 sqrt(alpha beta)
+    const double d = beta - alpha;
+    const double t = (d >= 0 ? 2.0 * gamma : -2.0 * gamma) / (fabs(d) + sqrt(d * d + 4.0 * g2));
     const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
