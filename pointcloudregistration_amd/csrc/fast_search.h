@@ -113,6 +113,8 @@ struct FastExact {
     uint32_t i[KC + 2];
     uint32_t rank[KC + 2];
     int n;
+    bool trusted;  // the walk could start and its ranking is verified: these ARE the best of the 3x3x3 cells (up to rank k)
+    int cell[3];   // the cell the walk was centred on
 };
 
 // timing build only (PCR_BLOCK_TIMES): the shader clock at stage boundaries of one search, kept in scalar registers
@@ -390,6 +392,10 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
             all->rank[j] = rk[j];
         }
         all->n = n_exact;
+        all->trusted = ok & verified;
+        all->cell[0] = cx;
+        all->cell[1] = cy;
+        all->cell[2] = cz;
     }
     if (win_pos) {
         uint32_t wp = PCR_NO_INDEX;

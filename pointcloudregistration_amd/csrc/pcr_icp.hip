@@ -489,11 +489,35 @@ __global__ void __launch_bounds__(256, MULTI ? PCR_MULTI_WAVES : PCR_STEP_WAVES)
 #endif
 template <int KC>
 __device__ PCR_FALLBACK_INLINE void fallback_forward(const StepArgs *__restrict__ Ap, double px, double py, double pz, double fmax_d2,
-                                                     double fwd_scale, int k, uint2 *my_rows, double *dF, uint32_t *j) {
+                                                     double fwd_scale, int k, uint2 *my_rows, double *dF, uint32_t *j,
+                                                     const FastExact<KC> *fx = nullptr) {
     TopK<KC> top;
     top.init(fmax_d2);
     const GridView G = Ap->tgt.v[0];  // (through the generic pointer)
-    lane_search<KC>(G, Ap->tgt.all, px, py, pz, px, py, pz, fmax_d2, fwd_scale, 0.0, top, my_rows);
+    // What the filtered walk found in its 3x3x3 cells is exact when it says so (its ranking verified) and merely did not
+    // SETTLE the query -- the K-th neighbour may lie farther out: the typical sample of a sparse stretch of a scan.  The
+    // fp64 walk then need not visit those cells again: it starts with that list and goes on from ring 2 -- provided both
+    // walks are centred on the same cell (the filtered walk picks its cell in fp32).
+    bool seeded = false;
+    if (fx && fx->trusted && fx->cell[0] == cell_coord(px, G.lo[0], G.inv_h, G.g[0]) &&
+        fx->cell[1] == cell_coord(py, G.lo[1], G.inv_h, G.g[1]) && fx->cell[2] == cell_coord(pz, G.lo[2], G.inv_h, G.g[2])) {
+        seeded = true;
+#pragma unroll
+        for (int a = 0; a < KC + 1; ++a)
+            if (a < fx->n && fx->i[a] != PCR_NO_INDEX && better(fx->d[a], fx->i[a], top.worst_d(), top.worst_i()))
+                top.insert(fx->d[a], fx->i[a]);
+    }
+    // (one call site for the shells: lanes of a wave that come here by different routes walk them together)
+    bool shells;
+    if (seeded) {
+        // the fp64 geometry often settles what the filtered walk's fp32 bounds, shrunk for safety, could not
+        const double qmargin = 9.094947017729282e-13 * (fabs(px) + fabs(py) + fabs(pz));
+        shells = !ring1_settles(G, px, py, pz, G.margin + qmargin, fwd_scale, top.worst_d(), fmax_d2);
+    } else {
+        shells = !ring1_pruned<KC, false>(G, Ap->tgt.all, px, py, pz, px, py, pz, fmax_d2, fwd_scale, 0.0, top, my_rows,
+                                          (const Rigid *)nullptr);
+    }
+    if (shells) grid_search<KC, false, false>(G, Ap->tgt.all, px, py, pz, px, py, pz, fmax_d2, fwd_scale, 0.0, top, 2);
     top.slot(k, *dF, *j);
 }
 __device__ PCR_FALLBACK_INLINE uint32_t fallback_reverse(const StepArgs *__restrict__ Ap, double qx, double qy, double qz, double sx,
@@ -561,6 +585,8 @@ __device__ __forceinline__ void fast_step_body(const StepArgs *__restrict__ Ap, 
         bool fwd_done = !fin;
         dF = fmax_d2;
         j = PCR_NO_INDEX;
+        FastExact<KC> fx;  // what the filtered walk knows exactly: the fp64 walk of an unsettled sample starts from it
+        fx.trusted = false;
         // what last iteration knew: its K-th distance, and how far a point can have moved since (both rounded up)
         double bound_d2 = PCR_INF;
         float *dk_io = A->dk_io;
@@ -571,11 +597,11 @@ __device__ __forceinline__ void fast_step_body(const StepArgs *__restrict__ Ap, 
         }
         if (fin)  // NeighborSet.back() = K-th nearest (:91-92)
             fwd_done = fast_ring1<KC, false, false>(GT, GT.pts, px, py, pz, px, py, pz, fmax_d2, bound_d2, fwd_scale, 0.0,
-                                                    GT.key_delta, A->k, 0.0, 0u, dF, j, my_rows, (const Rigid *)nullptr, nullptr, pf,
+                                                    GT.key_delta, A->k, 0.0, 0u, dF, j, my_rows, (const Rigid *)nullptr, &fx, pf,
                                                     nullptr, &qpos);
         q_known = fin & fwd_done & (qpos != PCR_NO_INDEX);  // the walk hands over q's position with its index
         if (__any(!fwd_done)) {
-            if (!fwd_done) fallback_forward<KC>(Ap, px, py, pz, fmax_d2, fwd_scale, A->k, my_rows, &dF, &j);
+            if (!fwd_done) fallback_forward<KC>(Ap, px, py, pz, fmax_d2, fwd_scale, A->k, my_rows, &dF, &j, fin ? &fx : nullptr);
         }
         found = fin && j != PCR_NO_INDEX && dF < fmax_d2;
         passF = found && dF < A->thr_fwd;  // strict < (:97)
