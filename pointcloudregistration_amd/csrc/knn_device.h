@@ -897,6 +897,7 @@ __device__ __forceinline__ void multi_lane_search(const MultiView &M, const Mult
             const double usx = XF ? wave_bcast(sx, src) : uqx, usy = XF ? wave_bcast(sy, src) : uqy,
                          usz = XF ? wave_bcast(sz, src) : uqz;
             const double uqm = extra_margin + 9.094947017729282e-13 * (fabs(usx) + fabs(usy) + fabs(usz));
+            const double umax_d2 = wave_bcast(max_d2, src);  // (a lane's reach may be its own: temporal bounds)
             TopK<KC> shared;
 #pragma unroll
             for (int j = 0; j < KC; ++j) {
@@ -910,8 +911,8 @@ __device__ __forceinline__ void multi_lane_search(const MultiView &M, const Mult
                 const GridView &g = M.v[l];
                 // other levels may have shrunk the K-th distance since this one was left open
                 const double b2 = level_box_dist2(g, usx, usy, usz, g.margin + uqm) * bound_scale;
-                if ((shared.worst_d() < b2) | (max_d2 <= b2)) continue;
-                coop_shells<KC, XF>(&M_mem->v[l], cand_all + (g.pts - M.all), uqx, uqy, uqz, usx, usy, usz, max_d2, bound_scale,
+                if ((shared.worst_d() < b2) | (umax_d2 <= b2)) continue;
+                coop_shells<KC, XF>(&M_mem->v[l], cand_all + (g.pts - M.all), uqx, uqy, uqz, usx, usy, usz, umax_d2, bound_scale,
                                     extra_margin, &shared, r_done, xf_mem);
             }
             if ((int)(threadIdx.x & 63u) == src) top = shared;

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--k", type=int, default=4)
     ap.add_argument("--occupancy", type=float, default=0.0, help="index target occupancy (0: library default)")
     ap.add_argument("--max-cells", type=int, default=0, help="cap on a level's cell table (0: library default)")
+    ap.add_argument("--fit", type=int, default=0, help="instead: a device-resident fit of this many iterations from a "
+                    "perturbed start; prints every iteration's kernel time (what the temporal bounds buy shows from the second)")
     a = ap.parse_args()
     from pointcloudregistration_amd import capi as pcr, synth
     src, tgt, Rm, t = synth.lidar_pair(a.n, 516, outlier_frac=a.outliers)
@@ -29,6 +31,21 @@ def main():
     tix = pcr.Index(ctx, pcr.Cloud(ctx, tgt), target_occupancy=a.occupancy, max_cells=a.max_cells)
     U = tix.unique_sq_dist()
     R, T = synth.colmajor(Rm), t
+    if a.fit > 0:
+        R0, T0 = synth.coarse_initial_transform(Rm, t, a.n)
+        fit = pcr.Fit(ctx, six, tix, a.k, U * 36.0, U * 4.0, conv=None, unique_sq_dist=U, traj_cap=a.fit)
+        fit.reset(R0, T0)
+        ctx.set_profiling(True, classes=[1])
+        per = []
+        for _ in range(a.fit):
+            fit.iterate()
+            ctx.synchronize()
+            per.append(round(ctx.read_kernel_times()["step"][0], 3))
+        res = fit.read()
+        print(json.dumps({"workload": f"C5 lidar {a.n}x{a.n}, {a.outliers:.0%} outliers, K={a.k}, device-resident fit",
+                          "iteration_ms": per, "kept_pairs_last": float(res["pairs"]), "mse_last": float(res["mse"]),
+                          "kernel": pcr.last_step_kernel()}))
+        return
     pcr.icp_step(ctx, six, tix, R, T, a.k, U * 36.0, U * 4.0, exact=False, want_outputs=False)   # warm-up
     ctx.set_profiling(True, classes=[1])
     for _ in range(a.steps):
