@@ -431,4 +431,136 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
     return ok & verified & settled;
 }
 
+// The search over all levels of an index, in three passes.
+//   1. The 3x3x3 walk on every level that can hold a better point.  A level the query lies outside of is entered
+//      at its cell nearest to the query.  Cheap, and afterwards the K-th distance is finite for all but the
+//      strangest queries.
+//   2. The levels that walk did not settle are continued with the shell search up to a radius of PCR_LANE_RMAX cells;
+//      its reach is bounded by what the OTHER levels found: a query in the hole a finer level left in a coarse one
+//      does not wander through the hole looking for K points of that level.
+//   3. The few queries that even that leaves open (hovering many cells away from a fine level's data) are finished
+//      one at a time by the whole wave (coop_shells).
+// Order in every pass: the levels whose box holds the query, finest first (that is where the nearest points are),
+// then the others from coarse to fine -- the boxes are nested, so that is by increasing distance -- each skipped
+// once its whole box is provably farther than the current K-th best.  One call site per pass (2 x levels slots).
+// Exact: every level is searched exactly against the running top-K, and the levels partition the cloud.
+// Called by ALL lanes of a wave (pass 3 shuffles); `active`: this lane has a query.  M_mem, xf_mem: the index's description
+// and (R,T) in DEVICE memory -- M and *xf may live in kernel arguments and registers, whose address cannot be handed
+// to the cooperative pass (not inlined) without the compiler copying all of it to every lane's scratch memory.
+// COOP = false: no pass 3 (pass 2 runs the shell search to its end in the lane; any subset of lanes may call).
+template <int KC, bool XF = false, bool COOP = true>
+__device__ __forceinline__ void multi_lane_search(const MultiView &M, const MultiView *M_mem, const Pt4 *__restrict__ cand_all, bool active, double qx,
+                                                  double qy, double qz, double sx, double sy, double sz, double max_d2,
+                                                  double bound_scale, double extra_margin, TopK<KC> &top, uint2 *rowtab,
+                                                  const Rigid *xf = nullptr, const Rigid *xf_mem = nullptr) {
+    const int L = M.levels;
+    const double qmargin = extra_margin + 9.094947017729282e-13 * (fabs(sx) + fabs(sy) + fabs(sz));
+    uint32_t holds = 0, open = 0;
+    if (active)
+        for (int it = 0; it < 2 * L; ++it) {
+            const int l = it < L ? L - 1 - it : it - L;
+            const GridView &g = M.v[l];
+            bool go;
+            if (it < L) {
+                const double pad = 2.0 * g.h;  // a query a couple of cells outside is as good as inside
+                go = (l == 0) | ((sx >= g.lo[0] - pad) & (sx <= g.hi[0] + pad) & (sy >= g.lo[1] - pad) & (sy <= g.hi[1] + pad) &
+                                 (sz >= g.lo[2] - pad) & (sz <= g.hi[2] + pad));
+                holds |= go ? 1u << l : 0u;
+            } else {
+                const double b2 = level_box_dist2(g, sx, sy, sz, g.margin + qmargin) * bound_scale;
+                go = !((holds >> l) & 1u) & !((top.worst_d() < b2) | (max_d2 <= b2));
+            }
+            if (go) {
+                DIAG_LANE_ADD(8 * (KC == 1) + 5, 1);  // ring walks
+                const Pt4 *lvl_pts = cand_all + (g.pts - M.all);
+                bool walked = false, settled = false;
+                if constexpr (KC <= 4) {
+                    // A level that carries fp32 shadows takes the FILTERED walk (fp32 keys select, fp64 decides and verifies):
+                    // its reach is what the levels before it left open -- the running K-th distance, ties included -- and its
+                    // exact, verified list (ranks 1..KC) is merged into the running one.  Whether the 3x3x3 cells settle
+                    // the level is then asked of the fp64 geometry (ring1_settles), as pass 2 does -- provided both walks
+                    // are centred on the same cell (this one picks its cell in fp32).  Anything else -- no shadows, a query
+                    // far outside the level's box, an unresolved near-tie -- takes the fp64 walk below.
+                    if (g.shadow) {
+                        FastExact<KC> fx;
+                        fx.trusted = false;
+                        const double reach = fmin(max_d2, top.worst_d() * (1.0 + 4.440892098500626e-16));
+                        const uint32_t delta =
+                            g.key_delta + (uint32_t)fmin((1.0 - bound_scale) * 1.1 * 4294967296.0 +
+                                                             2.0 * 65536.0 * 1.01 * extra_margin * g.key_sc + 2.0,
+                                                         1073741824.0);
+                        double dk;
+                        uint32_t ik;
+                        fast_ring1<KC, XF, false>(g, lvl_pts, qx, qy, qz, sx, sy, sz, reach, PCR_INF, bound_scale, extra_margin,
+                                                  delta, KC, 0.0, 0u, dk, ik, rowtab, xf, &fx);
+                        if (fx.trusted && fx.cell[0] == cell_coord(sx, g.lo[0], g.inv_h, g.g[0]) &&
+                            fx.cell[1] == cell_coord(sy, g.lo[1], g.inv_h, g.g[1]) &&
+                            fx.cell[2] == cell_coord(sz, g.lo[2], g.inv_h, g.g[2])) {
+#pragma unroll
+                            for (int a = 0; a < KC + 1; ++a)
+                                if (a < fx.n && fx.i[a] != PCR_NO_INDEX && better(fx.d[a], fx.i[a], top.worst_d(), top.worst_i()))
+                                    top.insert(fx.d[a], fx.i[a]);
+                            walked = true;
+                            settled = ring1_settles(g, sx, sy, sz, g.margin + qmargin, bound_scale, top.worst_d(), max_d2);
+                        }
+                    }
+                }
+                if (!walked)
+                    settled = ring1_pruned<KC, XF>(g, lvl_pts, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top,
+                                                   rowtab, xf);
+                open |= settled ? 0u : 1u << l;
+            }
+        }
+    if (__any(open != 0)) {
+        uint32_t left = 0;
+        for (int it = 0; it < 2 * L; ++it) {
+            const int l = it < L ? L - 1 - it : it - L;
+            const GridView &g = M.v[l];
+            bool go = ((open >> l) & 1u) & (((holds >> l) & 1u) == (it < L ? 1u : 0u));
+            if (go) {
+                const double b2 = level_box_dist2(g, sx, sy, sz, g.margin + qmargin) * bound_scale;
+                go = !((top.worst_d() < b2) | (max_d2 <= b2)) &&
+                     !ring1_settles(g, sx, sy, sz, g.margin + qmargin, bound_scale, top.worst_d(), max_d2);
+            }
+            if (go) {
+                const int r_done = grid_search<KC, true, XF, COOP ? PCR_LANE_RMAX : 0>(
+                    g, cand_all + (g.pts - M.all), qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, 2, xf);
+                left |= (uint32_t)r_done << (4 * l);  // (PCR_LANE_RMAX <= 15, at most 6 levels)
+            }
+        }
+        // ---- pass 3: one unfinished query at a time, by the whole wave ----
+        unsigned long long pending = COOP ? __ballot(left != 0) : 0ull;
+        while (pending) {
+            const int src = __ffsll(pending) - 1;
+            pending &= pending - 1ull;
+            DIAG_ADD(8 * (KC == 1) + 6, 1);  // cooperative searches
+            const uint32_t u_left = wave_bcast(left, src), u_holds = wave_bcast(holds, src);
+            const double uqx = wave_bcast(qx, src), uqy = wave_bcast(qy, src), uqz = wave_bcast(qz, src);
+            const double usx = XF ? wave_bcast(sx, src) : uqx, usy = XF ? wave_bcast(sy, src) : uqy,
+                         usz = XF ? wave_bcast(sz, src) : uqz;
+            const double uqm = extra_margin + 9.094947017729282e-13 * (fabs(usx) + fabs(usy) + fabs(usz));
+            const double umax_d2 = wave_bcast(max_d2, src);  // (a lane's reach may be its own: temporal bounds)
+            TopK<KC> shared;
+#pragma unroll
+            for (int j = 0; j < KC; ++j) {
+                shared.d[j] = wave_bcast(top.d[j], src);
+                shared.idx[j] = wave_bcast(top.idx[j], src);
+            }
+            for (int it = 0; it < 2 * L; ++it) {
+                const int l = it < L ? L - 1 - it : it - L;
+                const int r_done = (int)((u_left >> (4 * l)) & 15u);
+                if (!((r_done != 0) & (((u_holds >> l) & 1u) == (it < L ? 1u : 0u)))) continue;
+                const GridView &g = M.v[l];
+                // other levels may have shrunk the K-th distance since this one was left open
+                const double b2 = level_box_dist2(g, usx, usy, usz, g.margin + uqm) * bound_scale;
+                if ((shared.worst_d() < b2) | (umax_d2 <= b2)) continue;
+                coop_shells<KC, XF>(&M_mem->v[l], cand_all + (g.pts - M.all), uqx, uqy, uqz, usx, usy, usz, umax_d2, bound_scale,
+                                    extra_margin, &shared, r_done, xf_mem);
+            }
+            if ((int)(threadIdx.x & 63u) == src) top = shared;
+        }
+    }
+}
+
+
 }  // namespace pcr

@@ -1337,11 +1337,13 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
             BUILD_RC(compute_bounds(ctx, cloud->xyz_d, n, lvl_d, (uint8_t)(l + 1), lo, hi));
         }
         hipLaunchKernelGGL(pos_of_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ix->pts_d, n, ix->pos_of_d);
-        // ---- key-space shadows for the filtered search: one uniform grid only, and only while fp32 still resolves
-        // distances far below a cell (key_delta <= 2^24 of 2^32, i.e. grids up to ~14 000 cells along an axis)
-        if (M.levels == 1) {
-            GridView &V = M.v[0];
-            const uint64_t B_cells0 = ix->cells[0];
+        // ---- key-space shadows for the filtered search, level by level (each level has its own cell size, hence its own
+        // key scale), and only while fp32 still resolves distances far below a cell (key_delta <= 2^24 of 2^32, i.e. grids
+        // up to ~14 000 cells along an axis).  A single-level index with shadows takes the filtered step kernel; the levels
+        // of a nested one take the filtered walk inside multi_lane_search.
+        for (int l = 0; l < M.levels; ++l) {
+            GridView &V = M.v[l];
+            const uint64_t B_cells = ix->cells[l];
             const double sc = (double)41448.97f / V.h;  // KEY_CELL (fast_search.h) root units per cell: 2.5 h^2 <-> 2^32 keys
             double ext = 0;
             for (int a = 0; a < 3; ++a) ext = fmax(ext, V.hi[a] - V.lo[a]);
@@ -1349,11 +1351,12 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
             const double eps = 1.1920928955078125e-07 * (ext + 4.0 * V.h) * sc * 1.01;
             // |key - S d2| <= 2 sqrt(D) sqrt(3) eps + 3 eps^2 + 8*2^-24 D (fp32 arithmetic) + 4096 (truncation), D <= 2^32
             const double delta = 2.0 * 65536.0 * 1.7320508075688774 * eps * 1.01 + 3.0 * eps * eps + 2048.0 + 4096.0 + 64.0;
-            if (delta <= 16777216.0 && B_cells0 + 3 < (1ull << 30) && (uint64_t)n < (1ull << 28)) {  // 32-bit byte offsets
-                BUILD_HIP(hipMalloc(&ix->shadow_d, sizeof(float4) * (size_t)n));
-                hipLaunchKernelGGL(shadow_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const Pt4 *)ix->pts_d, n,
-                                   V.lo[0], V.lo[1], V.lo[2], sc, ix->shadow_d);
-                V.shadow = ix->shadow_d;
+            if (delta <= 16777216.0 && B_cells + 3 < (1ull << 30) && (uint64_t)V.n < (1ull << 28)) {  // 32-bit byte offsets
+                if (!ix->shadow_d) BUILD_HIP(hipMalloc(&ix->shadow_d, sizeof(float4) * (size_t)n));
+                const size_t off_l = (size_t)(V.pts - ix->pts_d);
+                hipLaunchKernelGGL(shadow_kernel, dim3((V.n + 255) / 256), dim3(256), 0, ctx->stream, (const Pt4 *)V.pts, V.n,
+                                   V.lo[0], V.lo[1], V.lo[2], sc, ix->shadow_d + off_l);
+                V.shadow = ix->shadow_d + off_l;
                 V.key_sc = sc;
                 V.key_S = sc * sc;
                 V.key_invS = 1.0 / V.key_S;

@@ -17,6 +17,7 @@
 #include <math.h>
 #include <vector>
 #include "knn_device.h"
+#include "fast_search.h"
 
 namespace pcr {
 
