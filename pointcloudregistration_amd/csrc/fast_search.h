@@ -466,6 +466,18 @@ __device__ __forceinline__ void multi_lane_search(const MultiView &M, const Mult
                 go = (l == 0) | ((sx >= g.lo[0] - pad) & (sx <= g.hi[0] + pad) & (sy >= g.lo[1] - pad) & (sy <= g.hi[1] + pad) &
                                  (sz >= g.lo[2] - pad) & (sz <= g.hi[2] + pad));
                 holds |= go ? 1u << l : 0u;
+                // The hole: every point of level l inside the box of level l+1 was handed down to it (assign_level_kernel),
+                // so level l holds nothing there.  A query deeper inside that box than the running K-th distance -- the
+                // finer levels have been searched by now -- has nothing to find in level l: no walk.  (A query in the
+                // densest part of a sweep lies in every level's box; without this it walks all of them.)
+                if (go && l + 1 < L) {
+                    const GridView &f = M.v[l + 1];
+                    const double m = fmin(fmin(fmin(sx - f.lo[0], f.hi[0] - sx), fmin(sy - f.lo[1], f.hi[1] - sy)),
+                                          fmin(sz - f.lo[2], f.hi[2] - sz)) -
+                                     (g.margin + qmargin);
+                    const double h2 = m > 0.0 ? m * m * bound_scale : 0.0;
+                    go = !((top.worst_d() < h2) | (max_d2 <= h2));
+                }
             } else {
                 const double b2 = level_box_dist2(g, sx, sy, sz, g.margin + qmargin) * bound_scale;
                 go = !((holds >> l) & 1u) & !((top.worst_d() < b2) | (max_d2 <= b2));
