@@ -496,7 +496,9 @@ __device__ __forceinline__ void multi_lane_search(const MultiView &M, const Mult
                     if (g.shadow) {
                         FastExact<KC> fx;
                         fx.trusted = false;
-                        const double reach = fmin(max_d2, top.worst_d() * (1.0 + 4.440892098500626e-16));
+                        // (strictly above the running K-th distance, also when that is zero: a tie at that distance
+                        // with a lower index must still be seen)
+                        const double reach = fmin(max_d2, top.worst_d() * (1.0 + 4.440892098500626e-16) + 4.9406564584124654e-324);
                         const uint32_t delta =
                             g.key_delta + (uint32_t)fmin((1.0 - bound_scale) * 1.1 * 4294967296.0 +
                                                              2.0 * 65536.0 * 1.01 * extra_margin * g.key_sc + 2.0,
