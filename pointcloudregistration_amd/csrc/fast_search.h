@@ -22,7 +22,10 @@ namespace pcr {
 constexpr uint32_t KEY_SENTINEL = 0xFFFFFFFFu;
 constexpr uint32_t KEY_DIST_MASK = 0xFFFFF000u;  // 20 bits of distance; 12 bits of payload: row slot << 8 | offset in row
 #ifndef PCR_FAST_U
-#define PCR_FAST_U 4
+#define PCR_FAST_U 6  // shadow records per trip of phase 2.  Measured on the 1 M x 1 M step (us per iteration): 3: 142.1, 4: 136.2,
+                      // 5: 133.4, 6: 132.7, 7: 134.4, 8: 136.8 -- fewer dependent trips against more wasted slots (the
+                      // optimum was 4 before the searches handed their winners over and the fallback was seeded; the
+                      // free-query K-NN kernel, unbounded and with three tries per trip, still does best with 4)
 #endif
 
 __device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b) { return __builtin_elementwise_add_sat(a, b); }
@@ -148,9 +151,9 @@ struct StageClock {
 //              caller then need not gather it again -- two dependent round trips saved per search
 // Returns false when this search cannot vouch for the result (not settled within ring 1, a cell row too long for the
 // payload, a query far outside the grid, an unresolved near-tie): the caller runs lane_search instead.
-// TRIES: see phase 2.  GV, RG: GridView and Rigid in whatever address space the caller keeps them (the step kernel: the constant one,
+// TRIES, U: see phase 2 (U: shadow records per trip).  GV, RG: GridView and Rigid in whatever address space the caller keeps them (the step kernel: the constant one,
 // so that every field is a scalar load at its point of use).
-template <int KC, bool XF, bool SEEDED, int TRIES = 1, class GV, class RG>
+template <int KC, bool XF, bool SEEDED, int TRIES = 1, int U = PCR_FAST_U, class GV, class RG>
 __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ exact_pts, double qx, double qy,
                                            double qz, double sx, double sy, double sz, double max_d2, double bound_d2,
                                            double bound_scale, double extra_margin, uint32_t delta, int k,
@@ -158,7 +161,6 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
                                            uint2 *rowtab, const RG *xf, FastExact<KC> *all = nullptr,
                                            StageClock *clk = nullptr, Pt4 *win = nullptr, uint32_t *win_pos = nullptr) {
     constexpr int KP = KC + 2;
-    constexpr int U = PCR_FAST_U;
     const uint32_t *__restrict__ cs = g.cs;
     const float4 *__restrict__ shadow = g.shadow;
     const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
