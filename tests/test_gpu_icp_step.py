@@ -110,3 +110,30 @@ def test_filtered_kernel_equals_the_fp64_walk_bit_for_bit(pcr, ctx):
                     assert (a[key] == b[key]).all(), (n, key, int((a[key] != b[key]).sum()))
         six.close()
         tix.close()
+
+
+def test_filtered_kernel_on_partial_scans_equals_the_fp64_walk(pcr, ctx):
+    """Two partial scans of uneven density (a tenth of the samples lie in stretches where the 3x3x3 cells do not settle
+    the search): the filtered kernel hands those to the fp64 walk SEEDED with its own verified list (shells from ring 2,
+    no second visit to ring 1).  Every index, flag and sum must equal the all-fp64 kernel's, for every k <= KC."""
+    from pointcloudregistration_amd import synth
+    scans, _ = synth.scan_sequence(2, 60000, 9000)
+    src, tgt = scans[1], scans[0]
+    six, tix = pcr.Index(ctx, pcr.Cloud(ctx, src), kind=pcr.INDEX_GRID), pcr.Index(ctx, pcr.Cloud(ctx, tgt), kind=pcr.INDEX_GRID)
+    U = tix.unique_sq_dist()
+    R, T = np.eye(3).reshape(9), np.zeros(3)
+    out = {}
+    try:
+        for mode in (1, 0):
+            pcr.lib().pcr_tune(5, mode)
+            out[mode] = [pcr.icp_step(ctx, six, tix, R, T, k, U * 36.0, U * 4.0, exact=ex) for k in (1, 2, 3, 4) for ex in (True, False)]
+            assert pcr.last_step_kernel() == ("icp_step_grid_kernel" if mode else "icp_step_fast_kernel<4>")
+    finally:
+        pcr.lib().pcr_tune(5, 0)
+    unpaired = int((out[0][7]["fwd"] == 0xFFFFFFFF).sum())
+    assert 2000 < unpaired < 30000, unpaired  # the data does have samples outside the overlap
+    for a, b in zip(out[1], out[0]):
+        for key in ("fwd", "rev", "keep", "partials"):
+            assert (a[key] == b[key]).all(), (key, int((a[key] != b[key]).sum()))
+    six.close()
+    tix.close()
