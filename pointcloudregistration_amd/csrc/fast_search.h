@@ -173,7 +173,8 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
     // the faces of the cell actually used).  The walk is exact for whatever cell it is centred on.
     float Qx = (float)((sx - g.lo[0]) * g.key_sc), Qy = (float)((sy - g.lo[1]) * g.key_sc),
           Qz = (float)((sz - g.lo[2]) * g.key_sc);
-    const float eps = g.key_eps + (float)(extra_margin * g.key_sc) * 1.0001f;
+    // (a literal zero margin -- every forward search -- folds away at compile time)
+    const float eps = extra_margin == 0.0 ? g.key_eps : g.key_eps + (float)(extra_margin * g.key_sc) * 1.0001f;
     // key_delta holds for queries within 4 cells of the box of the points (NaN fails every comparison)
     bool ok = (Qx >= -4.0f * KEY_CELL) & (Qx <= g.key_ext[0] + 4.0f * KEY_CELL) & (Qy >= -4.0f * KEY_CELL) &
               (Qy <= g.key_ext[1] + 4.0f * KEY_CELL) & (Qz >= -4.0f * KEY_CELL) & (Qz <= g.key_ext[2] + 4.0f * KEY_CELL);
@@ -330,9 +331,9 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
         }
     };
     // exact squared distance every candidate with a key >= `key` is at least at
+    const double floor_sc = g.key_invS * (1.0 - 9.313225746154785e-10);  // (uniform: one product, not one per call)
     auto floor_d2 = [&](uint32_t key) {
-        return key == KEY_SENTINEL ? PCR_INF
-                                   : (double)sat_sub(key & KEY_DIST_MASK, delta) * g.key_invS * (1.0 - 9.313225746154785e-10);
+        return key == KEY_SENTINEL ? PCR_INF : (double)sat_sub(key & KEY_DIST_MASK, delta) * floor_sc;
     };
     if constexpr (SEEDED) {
         ed[0] = seed_d;

@@ -36,6 +36,11 @@ struct StepDyn {
     double rinv[9];  // inverse of R (column-major), for locating q in the source grid
     double pivot_p[3], pivot_q[3];
     double rev_bound_scale, rev_extra_margin;
+    // key-space error bound of the filtered REVERSE search (fast_search.h) on the source's level-0 grid: the grid's own
+    // key_delta, plus |R v|^2 vs |v|^2 (1 - rev_bound_scale >= 3 * the orthogonality defect) over the key range, plus the
+    // rounding of the inverse map at the largest distance of interest.  Uniform over a launch: worked out here, once, by
+    // whoever makes the transform, not by every lane.
+    uint32_t rev_delta;
     uint32_t done;  // device-resident loop only: converged/stopped -- the remaining enqueued kernels return at once
     // device-resident loop only: no source point's image moved farther than this since the previous iteration
     // (+inf: unknown).  The K-th-neighbour distance is 1-Lipschitz in the query, so last iteration's distance plus this
@@ -47,8 +52,9 @@ struct StepDyn {
 //   c_src, c_tgt : centres of the clouds' bounds (the pivots only condition the sums)
 //   cloud_scale  : largest |coordinate| of either cloud
 // false: R is not a rotation to within 1e-3.
+//   src_key_sc, src_key_delta : GridView::key_sc / key_delta of the source index's level 0 (0: no shadows)
 PCR_HD inline bool make_dyn(const double *R, const double *T, const double *c_src, const double *c_tgt,
-                            double cloud_scale, StepDyn &D, double *defect_out) {
+                            double cloud_scale, double src_key_sc, uint32_t src_key_delta, StepDyn &D, double *defect_out) {
     for (int i = 0; i < 9; ++i) D.M.r[i] = R[i];
     for (int i = 0; i < 3; ++i) D.M.t[i] = T[i];
     double defect = 0;
@@ -62,6 +68,9 @@ PCR_HD inline bool make_dyn(const double *R, const double *T, const double *c_sr
     D.rev_bound_scale = (1.0 - 3.0 * defect) * (1.0 - 1.8189894035458565e-12);
     const double scale = fmax(fabs(T[0]) + fabs(T[1]) + fabs(T[2]), 0.0) + cloud_scale;
     D.rev_extra_margin = 3.637978807091713e-12 * scale;  // 2^-38: rounding of the inverse map
+    D.rev_delta = src_key_delta + (uint32_t)fmin((1.0 - D.rev_bound_scale) * 1.1 * 4294967296.0 +
+                                                     2.0 * 65536.0 * 1.01 * D.rev_extra_margin * src_key_sc + 2.0,
+                                                 1073741824.0);
     D.done = 0;
     D.disp_bound = __builtin_huge_valf();
     return ok;
@@ -633,12 +642,8 @@ __device__ __forceinline__ void fast_step_body(const StepArgs *__restrict__ Ap, 
             sz = D->rinv[2] * ux + D->rinv[5] * uy + D->rinv[8] * uz;
         }
         const bool rev_active = need_rev && isfinite(sx) && isfinite(sy) && isfinite(sz);
-        // key error of the reverse search: the source grid's own, plus |R v|^2 vs |v|^2 (1 - rev_bound_scale >= 3 * the
-        // orthogonality defect) over the key range, plus the rounding of the inverse map at the largest distance of interest
         const double rbs = D->rev_bound_scale, rem_ = D->rev_extra_margin;
-        const uint32_t rev_delta =
-            GS.key_delta + (uint32_t)fmin((1.0 - rbs) * 1.1 * 4294967296.0 + 2.0 * 65536.0 * 1.01 * rem_ * GS.key_sc + 2.0,
-                                          1073741824.0);
+        const uint32_t rev_delta = D->rev_delta;  // (make_dyn)
         bool rev_done = !rev_active;
         double dRv = dF;  // the reverse winner's distance to q (not used further) and index
         uint32_t rv = orig;
@@ -846,6 +851,8 @@ struct FitDev {
     StepDyn dyn;  // first member: the step kernels read it through a StepDyn pointer
     double c_src[3], c_tgt[3], cloud_scale;
     double src_rad;  // half the diagonal of the source's bounds: no source point is farther from c_src
+    double src_key_sc;       // the source index's key scale and error bound (make_dyn: StepDyn::rev_delta)
+    uint32_t src_key_delta;
     double uniq;  // CUniqueData of the target: scales the MSE thresholds
     pcr_convergence_params conv;
     int32_t conv_enabled;
@@ -950,7 +957,7 @@ __device__ __noinline__ void fit_solve_body(FitDev *__restrict__ F, const double
     F->state = state;
     // ---- next iteration's constants
     StepDyn next;
-    const bool ok = make_dyn(R, T, f.c_src, f.c_tgt, f.cloud_scale, next, nullptr);
+    const bool ok = make_dyn(R, T, f.c_src, f.c_tgt, f.cloud_scale, f.src_key_sc, f.src_key_delta, next, nullptr);
     if (!ok) {
         F->state = PCR_FIT_DEGENERATE;
         converged = true;
@@ -1165,7 +1172,8 @@ static int step_enqueue(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt
     double c_src[3], c_tgt[3], defect = 0;
     cloud_centre(src->cloud, c_src);
     cloud_centre(tgt->cloud, c_tgt);
-    PCR_REQUIRE(make_dyn(R, T, c_src, c_tgt, clouds_scale(src->cloud, tgt->cloud), D, &defect),
+    PCR_REQUIRE(make_dyn(R, T, c_src, c_tgt, clouds_scale(src->cloud, tgt->cloud), src->view.v[0].key_sc,
+                         src->view.v[0].shadow ? src->view.v[0].key_delta : 0u, D, &defect),
                 "%s: R must be a rotation to within 1e-3 (orthogonality defect %g)", who, defect);
     A.out_fwd = out_fwd_d;
     A.out_rev = out_rev_d;
@@ -1443,6 +1451,8 @@ int pcr_fit_create(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
     cloud_centre(src->cloud, I.c_src);
     cloud_centre(tgt->cloud, I.c_tgt);
     I.cloud_scale = clouds_scale(src->cloud, tgt->cloud);
+    I.src_key_sc = src->view.v[0].shadow ? src->view.v[0].key_sc : 0.0;
+    I.src_key_delta = src->view.v[0].shadow ? src->view.v[0].key_delta : 0u;
     {
         double d2 = 0;
         for (int a = 0; a < 3; ++a) d2 += (src->cloud->hi[a] - src->cloud->lo[a]) * (src->cloud->hi[a] - src->cloud->lo[a]);
@@ -1524,7 +1534,7 @@ int pcr_fit_reset(pcr_fit *f, const double R[9], const double T[3]) {
     PCR_HIP(hipSetDevice(f->ctx->device));
     FitDev I = f->init;
     double defect = 0;
-    PCR_REQUIRE(make_dyn(R, T, I.c_src, I.c_tgt, I.cloud_scale, I.dyn, &defect),
+    PCR_REQUIRE(make_dyn(R, T, I.c_src, I.c_tgt, I.cloud_scale, I.src_key_sc, I.src_key_delta, I.dyn, &defect),
                 "pcr_fit_reset: R must be a rotation to within 1e-3 (orthogonality defect %g)", defect);
     // CDefaultConvergenceCriteria::__init (DefaultConvergenceCriterial.cpp:21-25); m_PreRot is uninitialised in the
     // reference: NaN makes the first transformation test false, as garbage far from a rotation does
