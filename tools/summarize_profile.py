@@ -62,10 +62,12 @@ def main():
         for (k, _d, c), v in disp.items():
             per[k][c].append(v)
 
-    sys.path.insert(0, root)
-    from pointcloudregistration_amd.stamp import kernel_sources_stamp
+    # the fingerprint profile.sh took on the GPU box when the counters were collected -- never the sources' state at the time
+    # this summary is written (a re-summarised old collection must not pass for a fresh one)
+    stamp_file = os.path.join(src, "kernel_sources_stamp.txt")
+    stamp = open(stamp_file).read().strip() if os.path.exists(stamp_file) else None
     out = {"tag": tag, "note": "per-launch means over the dispatches of one `bench.py --steps 30 --warmup 3` run per counter pass",
-           "kernel_sources_stamp": kernel_sources_stamp(),  # bench.py quotes these counters only while this matches
+           "kernel_sources_stamp": stamp,  # bench.py quotes these counters only while this matches
            "kernels": {}}
     for k, cs in sorted(per.items()):
         e = dict(meta[k])
