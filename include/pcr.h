@@ -304,6 +304,14 @@ int pcr_fit_create(pcr_ctx *ctx, const pcr_index *src_index, const pcr_index *tg
 /* replace the sample set by a HOST list of source indices (copied; the fit owns the device copy).  An empty list
  * (m = 0) yields zero sums.  Synchronises the stream. */
 int pcr_fit_set_samples(pcr_fit *fit, const uint32_t *sample_idx, uint32_t m);
+/* DEBUG / parity runs only: let every iteration of the device-resident loop also write what the reference's loop hands
+ * from stage to stage each iteration (the pair set of IterativeFit.cpp:138-158, CorrespondenceEstimationClosestPoints.cpp:
+ * 84-106) -- per sample the forward index, the reverse index and the keep flag, with pcr_icp_step_d's slot convention
+ * (sample list: slot = position in the list, m entries; sample range: slot = source index, n entries).  Device
+ * pointers, each nullable; all NULL switches the outputs off again (the default: a benchmark leaves them off).  Each
+ * iteration overwrites the previous one's: enqueue one iteration, copy, enqueue the next.  Takes effect from the next
+ * enqueued iteration (also inside a pcr_fit_batch of which the fit is a member); drops a captured graph. */
+int pcr_fit_set_debug_outputs(pcr_fit *fit, uint32_t *out_fwd_d, uint32_t *out_rev_d, uint8_t *out_keep_d);
 /* (re)start from the initial transform: iteration 0, criteria state as freshly constructed */
 int pcr_fit_reset(pcr_fit *fit, const double R[9], const double T[3]);
 int pcr_fit_enqueue_step(pcr_fit *fit);

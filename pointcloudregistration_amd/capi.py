@@ -82,6 +82,7 @@ SYMBOLS = {
     "pcr_fit_create": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, _vp,
                                  C.c_double, C.c_uint32, C.POINTER(_vp)]),
     "pcr_fit_set_samples": (C.c_int, [_vp, _up, C.c_uint32]),
+    "pcr_fit_set_debug_outputs": (C.c_int, [_vp, _vp, _vp, _vp]),
     "pcr_fit_reset": (C.c_int, [_vp, _dp, _dp]),
     "pcr_fit_enqueue_step": (C.c_int, [_vp]),
     "pcr_fit_partials_d": (_vp, [_vp]),
@@ -424,6 +425,16 @@ class Fit:
     def set_samples(self, sample_idx):
         a = np.ascontiguousarray(sample_idx, np.uint32)
         _check(lib().pcr_fit_set_samples(self.h, _u(a), len(a)), "pcr_fit_set_samples")
+
+    def set_debug_outputs(self, out_fwd_t=None, out_rev_t=None, out_keep_t=None):
+        """parity runs: every later iteration also writes fwd/rev (uint32) and keep (uint8) per sample into these CUDA
+        tensors (slot convention of icp_step_d); all None switches them off.  The tensors must outlive their use."""
+        self._dbg = (out_fwd_t, out_rev_t, out_keep_t)
+
+        def p(t):
+            return _vp(t.data_ptr()) if t is not None else None
+        _check(lib().pcr_fit_set_debug_outputs(self.h, p(out_fwd_t), p(out_rev_t), p(out_keep_t)),
+               "pcr_fit_set_debug_outputs")
 
     def reset(self, R, T):
         R, T = _rt(R, T)

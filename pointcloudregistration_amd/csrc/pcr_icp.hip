@@ -5,10 +5,11 @@
 // TransformationEstimationSVD2.cpp:33-103, DefaultConvergenceCriterial.cpp:46-65):
 //   copy + transform the whole source, build a KD-tree on it, then serially per sample:
 //   forward K-NN, reverse 1-NN, two gates, push_back; later 5 more passes for centroids and H.
-// Here: one streaming transform kernel, then ONE kernel in which each lane owns a sample and does
-// transform -> forward K-NN (target grid) -> reverse 1-NN (source grid, transformed candidates)
-// -> gates -> masked fp64 accumulation, followed by a wave/block tree reduction; a second tiny
-// kernel folds the block partials in a fixed order (bitwise reproducible run to run).
+// Here: ONE kernel per iteration in which each lane owns a sample and does
+// transform -> forward K-NN (target grid) -> reverse 1-NN (source grid; candidates moved by (R,T) as they are read: no
+// transformed copy of the source exists) -> gates -> masked fp64 accumulation, followed by a block reduction through
+// LDS; the kernel's last blocks fold the block partials in a fixed order (bitwise reproducible run to run) and, in a
+// device-resident fit on one GPU, run the 3x3 solve and the convergence criteria on the spot.
 #include <math.h>
 #include <string.h>
 #include <vector>
@@ -149,6 +150,14 @@ __device__ __forceinline__ void st_agent(double *p, double v) {
 __device__ __forceinline__ double ld_agent(const double *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// A lane that has issued st_agent stores and is about to let ANOTHER lane publish them (a ticket drawn after a block
+// barrier) waits here until memory has acknowledged them.  A workgroup barrier does not do that on gfx950: s_barrier
+// waits for waves, not for their outstanding stores, and the relaxed ticket atomic travels on another channel -- without
+// this wait the ticket can be seen by a block on another XCD while a partial sum is still in flight, and that block folds
+// whatever the slot held before (last launch's value: close enough, in a converging fit, to pass a 1e-9 test).  The
+// stores being write-through (sc1) themselves, nothing needs writing back: no release fence, only the wait.
+// tests/test_isa_fold_order.py checks the shipped code object for it.
+__device__ __forceinline__ void wait_stores_acked() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // 17 per-lane values -> one value per block and column, stored column-major [17][nblocks] so that the fold
 // reads coalesced.  Through LDS, not shuffles: every lane parks its 17 values (17 conflict-free writes), then 16 lanes
@@ -188,6 +197,7 @@ __device__ __forceinline__ void block_reduce17(double (&v)[17], double *__restri
         s16 += __shfl_xor(s16, 1, 64);
         if (tid == 0u) st_agent(&out[(size_t)16 * nblocks + block], s16);
     }
+    wait_stores_acked();  // before any barrier behind which a ticket is drawn (fold_in_kernel)
 }
 
 template <class DY>
@@ -229,6 +239,7 @@ __device__ __forceinline__ void fold17(const double *x, size_t stride, uint32_t 
     s += __shfl_xor(s, 2, 64);
     s += __shfl_xor(s, 1, 64);
     if (tid < 136u && sub == 0u) st_agent(&out[(size_t)col * out_stride], s);
+    wait_stores_acked();  // the caller's next barrier hands these to another block's fold, or to the solve
 }
 
 #ifdef PCR_BLOCK_TIMES
@@ -241,9 +252,10 @@ __device__ __forceinline__ void fold_in_kernel(AP A, uint32_t lb, uint32_t nb) {
     if (!tickets) return;
     __shared__ uint32_t s_last;
     const uint32_t ngroups = (nb + 63u) >> 6, g = lb >> 6;
-    // The block's partials are device-scope stores by its threads 0..16; the barrier (which waits for them to
-    // complete) orders them before thread 0's ticket, a device-scope atomic.  The block that draws the last ticket of a
-    // group therefore reads complete partials (device-scope loads) -- no fence anywhere.
+    // The block's partials are device-scope write-through stores, and every lane that issued one has waited for
+    // memory's acknowledgement (wait_stores_acked, at the end of block_reduce17 / fold17) BEFORE this barrier; thread 0's
+    // ticket, a device-scope atomic, is drawn after it.  A block that sees the last ticket of a group therefore reads
+    // complete partials with device-scope loads (which miss the XCD's L2 by construction) -- no cache-wide fence anywhere.
     __syncthreads();
     if (threadIdx.x == 0)
         s_last = __hip_atomic_fetch_add(&tickets[1u + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
@@ -876,7 +888,7 @@ __device__ __noinline__ void fit_solve_body(FitDev *__restrict__ F, const double
     // one thread, and every load from device memory costs it a microsecond: fetch the sums and the whole state at once
     // (all loads in flight together, the `done` flag among them) and read the copy from here on; stores go to *F
     double part[17];
-    for (int i = 0; i < 17; ++i) part[i] = partials[i];
+    for (int i = 0; i < 17; ++i) part[i] = ld_agent(&partials[i]);  // (written by other lanes of this block: fold17)
     const FitDev f = *F;
     if (f.dyn.done) return;
     const uint32_t it = f.iteration + 1;  // the reference counts from 1 (IterativeFit.cpp:121-123)
@@ -1523,6 +1535,18 @@ int pcr_fit_set_samples(pcr_fit *f, const uint32_t *sample_idx, uint32_t m) {
     f->nb = nb;
     PCR_HIP(fit_alloc_fold(f));
     fit_upload_args(f);
+    PCR_HIP(hipGetLastError());
+    return PCR_OK;
+}
+
+int pcr_fit_set_debug_outputs(pcr_fit *f, uint32_t *out_fwd_d, uint32_t *out_rev_d, uint8_t *out_keep_d) {
+    PCR_REQUIRE(f, "pcr_fit_set_debug_outputs: NULL argument");
+    PCR_HIP(hipSetDevice(f->ctx->device));
+    fit_drop_graph(f);  // (a captured launch of a kernel that takes its arguments by value holds the old pointers)
+    f->args.out_fwd = out_fwd_d;
+    f->args.out_rev = out_rev_d;
+    f->args.out_keep = out_keep_d;
+    fit_upload_args(f);  // stream-ordered: iterations already enqueued keep what they were enqueued with
     PCR_HIP(hipGetLastError());
     return PCR_OK;
 }
