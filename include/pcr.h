@@ -249,13 +249,18 @@ int pcr_icp_pivots(const pcr_index *src_index, const pcr_index *tgt_index, const
  * allocations: the call performs no hipMalloc / hipFree, whatever its arguments.  Limits: m <= PCR_NOALLOC_MAX_SAMPLES
  * (larger m is rejected with PCR_E_INVALID: split the samples into ranges and add the partials); all calls on one
  * GPU share that GPU's array, so two calls that overlap in time on one GPU (different contexts or streams) race --
- * serialise them.  Inputs and outputs are the caller's, as for pcr_icp_step_d. */
+ * serialise them.  The call is legal under HIP stream capture (kernel and memset nodes only; tested in global capture
+ * mode, where any allocation would invalidate the capture).  Inputs and outputs are the caller's, as for pcr_icp_step_d. */
 #define PCR_NOALLOC_MAX_SAMPLES 4194304u
 int pcr_icp_step_noalloc_d(pcr_ctx *ctx, const pcr_index *src_index, const pcr_index *tgt_index,
                            const uint32_t *sample_idx_d /*nullable*/, uint32_t sample_begin, uint32_t m,
                            const double R[9], const double T[3], uint32_t k, double thr_fwd_sq, double thr_rev_sq,
                            uint32_t flags, double *partials_d, uint32_t *out_fwd_d, uint32_t *out_rev_d,
                            uint8_t *out_keep_d);
+/* TEST HOOK of the entry point above (no reference counterpart): leaves the fixed scratch's fold tickets of the
+ * context's GPU non-zero, as a launch that died half-way would -- the next pcr_icp_step_noalloc_d must still be right,
+ * because it clears them itself at the start of every call (tests/test_zz_no_alloc.py). */
+int pcr_noalloc_debug_poison_tickets(pcr_ctx *ctx);
 
 /* ---- the same 17 sums over an EXPLICIT pair list ------------------------------------------
  * Replaces compute3DCentroid x2 + __deMean + __buildPointPairMatrix + H = A*B^T

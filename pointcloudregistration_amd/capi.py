@@ -77,6 +77,7 @@ SYMBOLS = {
                                  C.c_double, C.c_uint32, _vp, _vp, _vp, _vp]),
     "pcr_icp_step_noalloc_d": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _dp, _dp, C.c_uint32, C.c_double,
                                          C.c_double, C.c_uint32, _vp, _vp, _vp, _vp]),
+    "pcr_noalloc_debug_poison_tickets": (C.c_int, [_vp]),
     "pcr_last_step_kernel": (C.c_char_p, []),
     "pcr_icp_pivots": (C.c_int, [_vp, _vp, _dp, _dp, _dp, _dp]),
     "pcr_fit_create": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, _vp,

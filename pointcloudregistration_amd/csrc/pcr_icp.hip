@@ -12,6 +12,7 @@
 // device-resident fit on one GPU, run the 3x3 solve and the convergence criteria on the spot.
 #include <math.h>
 #include <string.h>
+#include <mutex>
 #include <vector>
 #include "knn_device.h"
 #include "fast_search.h"
@@ -1285,16 +1286,24 @@ struct NoAllocScratch {
 static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocScratch)];
 constexpr int NOALLOC_MAX_DEVICES = 64;
 static NoAllocScratch *g_noalloc_ptr[NOALLOC_MAX_DEVICES];  // per device: that device's copy of `scratch`
+static std::mutex g_noalloc_mutex;
 
 }  // extern "C"
 namespace pcr {
 int noalloc_scratch_init(int device) {
     if (device < 0 || device >= NOALLOC_MAX_DEVICES) return PCR_OK;  // such a device simply has no no-alloc entry point
+    // contexts may be created from several threads at once: one lookup per device, published under the lock
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
     if (g_noalloc_ptr[device]) return PCR_OK;
     void *p = nullptr;
-    PCR_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    PCR_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));  // (that device is current: pcr_ctx_create set it)
     g_noalloc_ptr[device] = (NoAllocScratch *)p;
     return PCR_OK;
+}
+static NoAllocScratch *noalloc_scratch_of(int device) {
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    return g_noalloc_ptr[device];
 }
 }  // namespace pcr
 extern "C" {
@@ -1308,12 +1317,27 @@ int pcr_icp_step_noalloc_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *
                 "pcr_icp_step_noalloc_d: m=%u exceeds PCR_NOALLOC_MAX_SAMPLES=%u (the fixed scratch of this entry point); "
                 "use pcr_icp_step_d, or split the samples into ranges and add the partials",
                 m, PCR_NOALLOC_MAX_SAMPLES);
-    NoAllocScratch *S = ctx->device < NOALLOC_MAX_DEVICES ? g_noalloc_ptr[ctx->device] : nullptr;
+    NoAllocScratch *S = noalloc_scratch_of(ctx->device);
     PCR_REQUIRE(S, "pcr_icp_step_noalloc_d: no scratch on device %d (set up by pcr_ctx_create)", ctx->device);
     PCR_HIP(hipSetDevice(ctx->device));
+    // The fold's tickets must start at zero.  Every launch that completes leaves them so -- but the array lives as long
+    // as the process, and a launch that died half-way (or two calls that overlapped against the documented rule) would
+    // otherwise poison every later call on this GPU: clear them here, stream-ordered, every call.  A memset node
+    // allocates nothing and is legal under stream capture.
+    PCR_HIP(hipMemsetAsync(S->tickets, 0, sizeof S->tickets, ctx->stream));
     return step_enqueue(ctx, src, tgt, sample_idx_d, sample_begin, m, R, T, k, thr_fwd_sq, thr_rev_sq, flags, partials_d,
                         out_fwd_d, out_rev_d, out_keep_d, &S->step, S->group_partials, S->tickets, S->block_partials,
                         "pcr_icp_step_noalloc_d");
+}
+
+// test hook (not in include/pcr.h): leaves this GPU's fixed tickets non-zero, as a launch that died mid-fold would
+int pcr_noalloc_debug_poison_tickets(pcr_ctx *ctx) {
+    PCR_REQUIRE(ctx, "pcr_noalloc_debug_poison_tickets: NULL argument");
+    NoAllocScratch *S = noalloc_scratch_of(ctx->device);
+    PCR_REQUIRE(S, "pcr_noalloc_debug_poison_tickets: no scratch on device %d", ctx->device);
+    PCR_HIP(hipSetDevice(ctx->device));
+    PCR_HIP(hipMemsetAsync(S->tickets, 0x01, sizeof S->tickets, ctx->stream));
+    return PCR_OK;
 }
 
 static int step_host_impl(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, const uint32_t *sample_idx, uint32_t m,
@@ -1511,29 +1535,50 @@ int pcr_fit_set_samples(pcr_fit *f, const uint32_t *sample_idx, uint32_t m) {
     PCR_HIP(hipSetDevice(f->ctx->device));
     PCR_HIP(hipStreamSynchronize(f->ctx->stream));  // nothing in flight may still read the old list or partials
     fit_drop_graph(f);                              // (a captured launch holds the old grid size)
-    if (f->samples_d) hipFree(f->samples_d);
-    f->samples_d = nullptr;
+    // allocate everything the new sample set needs FIRST; the fit changes only once all of it exists (a failure leaves
+    // it exactly as it was, its device-side arguments still pointing at live memory)
     const uint32_t nb = m ? (m + 255) / 256 : 0;
-    if (nb > f->nb) {
+    const size_t ng = (nb + 63u) / 64u;
+    uint32_t *samples_new = nullptr, *tickets_new = nullptr;
+    double *bp_new = nullptr, *gp_new = nullptr;
+    float *dk_new = nullptr;
+    hipError_t e = hipSuccess;
+    if (nb > f->nb) e = hipMalloc(&bp_new, sizeof(double) * 17 * (size_t)nb);
+    if (e == hipSuccess && m) e = hipMalloc(&samples_new, sizeof(uint32_t) * (size_t)m);
+    if (e == hipSuccess && m) e = hipMalloc(&dk_new, sizeof(float) * (size_t)m);
+    if (e == hipSuccess) e = hipMalloc(&gp_new, sizeof(double) * 17 * (ng ? ng : 1));
+    if (e == hipSuccess) e = hipMalloc(&tickets_new, sizeof(uint32_t) * (1 + ng));
+    if (e == hipSuccess && m) e = hipMemcpy(samples_new, sample_idx, sizeof(uint32_t) * (size_t)m, hipMemcpyHostToDevice);
+    if (e == hipSuccess && m) e = hipMemsetD32Async((hipDeviceptr_t)dk_new, 0x7f800000, m, f->ctx->stream);  // +inf: nothing known
+    if (e == hipSuccess) e = hipMemsetAsync(tickets_new, 0, sizeof(uint32_t) * (1 + ng), f->ctx->stream);
+    if (e != hipSuccess) {
+        if (bp_new) hipFree(bp_new);
+        if (samples_new) hipFree(samples_new);
+        if (dk_new) hipFree(dk_new);
+        if (gp_new) hipFree(gp_new);
+        if (tickets_new) hipFree(tickets_new);
+        PCR_HIP(e);
+    }
+    if (bp_new) {
         hipFree(f->block_partials_d);
-        f->block_partials_d = nullptr;
-        PCR_HIP(hipMalloc(&f->block_partials_d, sizeof(double) * 17 * (size_t)nb));
-        f->args.block_partials = f->block_partials_d;
+        f->block_partials_d = bp_new;
+        f->args.block_partials = bp_new;
     }
+    if (f->samples_d) hipFree(f->samples_d);
     if (f->dk_d) hipFree(f->dk_d);
-    f->dk_d = nullptr;
-    if (m) {
-        PCR_HIP(hipMalloc(&f->samples_d, sizeof(uint32_t) * (size_t)m));
-        PCR_HIP(hipMemcpy(f->samples_d, sample_idx, sizeof(uint32_t) * (size_t)m, hipMemcpyHostToDevice));
-        PCR_HIP(hipMalloc(&f->dk_d, sizeof(float) * (size_t)m));
-        PCR_HIP(hipMemsetD32Async((hipDeviceptr_t)f->dk_d, 0x7f800000, m, f->ctx->stream));  // +inf: nothing known
-    }
+    if (f->group_partials_d) hipFree(f->group_partials_d);
+    if (f->tickets_d) hipFree(f->tickets_d);
+    f->samples_d = samples_new;
+    f->dk_d = dk_new;
+    f->group_partials_d = gp_new;
+    f->tickets_d = tickets_new;
+    f->args.group_partials = gp_new;
+    f->args.tickets = tickets_new;
     f->args.dk_io = f->dk_d;
     f->args.sample_idx = f->samples_d;
     f->args.sample_begin = 0;
     f->args.m = m;
     f->nb = nb;
-    PCR_HIP(fit_alloc_fold(f));
     fit_upload_args(f);
     PCR_HIP(hipGetLastError());
     return PCR_OK;

@@ -132,10 +132,11 @@ __global__ void __launch_bounds__(256) reject_stat_brute_kernel(MultiView src, M
 }
 
 // out[0] = sum_i f(d_i), f = identity (center == NULL) or (d - *center)^2; out[1] = count_slot ? P : untouched;
-// out[2..16] = 0.  One block, fixed order.  `out` is a 17-double exchange buffer: in a sharded run every rank's is
-// summed (the all-reduce the fit loop uses for its 17 partials) before finish_stat_kernel divides.
+// out[2] = failed (1.0: this rank could not do its share -- it contributes no pair, and the flag, summed with the rest,
+// tells EVERY rank so); out[3..16] = 0.  One block, fixed order.  `out` is a 17-double exchange buffer: in a sharded
+// run every rank's is summed (the all-reduce the fit loop uses for its 17 partials) before finish_stat_kernel divides.
 __global__ void __launch_bounds__(1024) sum_kernel(const double *__restrict__ d, uint32_t P,
-                                                   const double *__restrict__ center, int count_slot,
+                                                   const double *__restrict__ center, int count_slot, int failed,
                                                    double *__restrict__ out) {
     __shared__ double sm[1024];
     const double c = center ? *center : 0.0;
@@ -152,16 +153,19 @@ __global__ void __launch_bounds__(1024) sum_kernel(const double *__restrict__ d,
     }
     if (threadIdx.x == 0) out[0] = sm[0];
     if (threadIdx.x == 1 && count_slot) out[1] = (double)P;
-    if (threadIdx.x >= 2 && threadIdx.x < 17) out[threadIdx.x] = 0.0;
+    if (threadIdx.x == 2) out[2] = failed ? 1.0 : 0.0;
+    if (threadIdx.x >= 3 && threadIdx.x < 17) out[threadIdx.x] = 0.0;
 }
 
 // stat[which] = x[0] / count: the mean (:34-35), then the population variance (:36-37), over ALL ranks' pairs.
-// total_out (nullable) keeps the pair count for the second call, whose exchange buffer no longer carries it.
+// total_out (nullable) keeps the pair count for the second call, whose exchange buffer no longer carries it;
+// failed_io accumulates the ranks' failure flags of both exchanges.
 __global__ void finish_stat_kernel(const double *__restrict__ x, const double *__restrict__ count, double *__restrict__ stat,
-                                   int which, double *__restrict__ total_out) {
+                                   int which, double *__restrict__ total_out, double *__restrict__ failed_io) {
     const double n = *count;
-    stat[which] = x[0] / n;
+    stat[which] = x[0] / n;  // (no pair on any rank: NaN here, PCR_E_INVALID on the host)
     if (total_out) *total_out = n;
+    *failed_io = (which == 0 ? 0.0 : *failed_io) + x[2];
 }
 
 __global__ void __launch_bounds__(256) reject_mask_kernel(const double *__restrict__ d, uint32_t P,
@@ -194,39 +198,53 @@ static int reject_impl(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt,
     double *pp_d = nullptr, *pq_d = nullptr, *d_d = nullptr;
     uint8_t *k_d = nullptr;
     const size_t bytes = sizeof(double) * 3 * (size_t)(P ? P : 1);
-    int reduce_rc = PCR_OK;
     hipError_t e = hipMalloc(&pp_d, bytes);
     if (e == hipSuccess) e = hipMalloc(&pq_d, bytes);
     if (e == hipSuccess) e = hipMalloc(&d_d, sizeof(double) * (P ? P : 1));
     if (e == hipSuccess) e = hipMalloc(&k_d, P ? P : 1);
     if (e == hipSuccess && P) e = hipMemcpyAsync(pp_d, pair_p, bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && P) e = hipMemcpyAsync(pq_d, pair_q, bytes, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) {
-        const uint32_t nb = (P + 255) / 256;
+    // A sharded run promises every rank that the hook is entered EXACTLY TWICE on every rank (the others wait in the
+    // collective otherwise).  A rank that cannot do its share -- an allocation or a copy failed -- therefore still goes
+    // through both exchanges: it contributes no pair and a failure flag (slot 2), which, summed over the ranks, makes
+    // EVERY rank return the same error.  Without a hook a local failure simply returns.
+    const bool local_fail = e != hipSuccess;
+    const hipError_t local_err = e;
+    if (local_fail && !reduce) {
+        if (pp_d) hipFree(pp_d);
+        if (pq_d) hipFree(pq_d);
+        if (d_d) hipFree(d_d);
+        if (k_d) hipFree(k_d);
+        PCR_HIP(local_err);
+    }
+    const uint32_t Pw = local_fail ? 0u : P;  // pairs this rank works on
+    int reduce_rc = PCR_OK;
+    {
+        const uint32_t nb = (Pw + 255) / 256;
         const uint32_t *qorder = nullptr;
-        if (src->kind == PCR_INDEX_GRID && P >= 2048) {
-            uint32_t *o = (uint32_t *)ctx_scratch(ctx, 4, sizeof(uint32_t) * (size_t)P);
-            if (o && coarse_query_order(ctx, tgt->view.v[0], pq_d, P, o) == PCR_OK) qorder = o;
+        if (src->kind == PCR_INDEX_GRID && Pw >= 2048) {
+            uint32_t *o = (uint32_t *)ctx_scratch(ctx, 4, sizeof(uint32_t) * (size_t)Pw);
+            if (o && coarse_query_order(ctx, tgt->view.v[0], pq_d, Pw, o) == PCR_OK) qorder = o;
         }
 #define LAUNCH_STAT(KC)                                                                                              \
     do {                                                                                                             \
         if (src->kind == PCR_INDEX_GRID && src->view.levels > 1 && tgt->view.levels > 1)                            \
             hipLaunchKernelGGL((reject_stat_kernel<KC, true, true>), dim3(nb), dim3(256), 0, ctx->stream, src->view, \
-                               tgt->view, (const double *)pp_d, (const double *)pq_d, qorder, P, (int)msn, msd, d_d); \
+                               tgt->view, (const double *)pp_d, (const double *)pq_d, qorder, Pw, (int)msn, msd, d_d); \
         else if (src->kind == PCR_INDEX_GRID && src->view.levels > 1)                                                \
             hipLaunchKernelGGL((reject_stat_kernel<KC, true, false>), dim3(nb), dim3(256), 0, ctx->stream, src->view, \
-                               tgt->view, (const double *)pp_d, (const double *)pq_d, qorder, P, (int)msn, msd, d_d); \
+                               tgt->view, (const double *)pp_d, (const double *)pq_d, qorder, Pw, (int)msn, msd, d_d); \
         else if (src->kind == PCR_INDEX_GRID && tgt->view.levels > 1)                                                \
             hipLaunchKernelGGL((reject_stat_kernel<KC, false, true>), dim3(nb), dim3(256), 0, ctx->stream, src->view, \
-                               tgt->view, (const double *)pp_d, (const double *)pq_d, qorder, P, (int)msn, msd, d_d); \
+                               tgt->view, (const double *)pp_d, (const double *)pq_d, qorder, Pw, (int)msn, msd, d_d); \
         else if (src->kind == PCR_INDEX_GRID)                                                                        \
             hipLaunchKernelGGL((reject_stat_kernel<KC, false, false>), dim3(nb), dim3(256), 0, ctx->stream, src->view, \
-                               tgt->view, (const double *)pp_d, (const double *)pq_d, qorder, P, (int)msn, msd, d_d); \
+                               tgt->view, (const double *)pp_d, (const double *)pq_d, qorder, Pw, (int)msn, msd, d_d); \
         else                                                                                                         \
             hipLaunchKernelGGL(reject_stat_brute_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, src->view,         \
-                               tgt->view, (const double *)pp_d, (const double *)pq_d, P, (int)msn, msd, d_d);       \
+                               tgt->view, (const double *)pp_d, (const double *)pq_d, Pw, (int)msn, msd, d_d);      \
     } while (0)
-        if (P) {
+        if (Pw) {
             ProfScope ps(ctx, PCR_PROF_KNN);  // (timed with the K-NN class: two K = MSN searches per pair)
             if (msn <= 4)
                 LAUNCH_STAT(4);
@@ -238,26 +256,30 @@ static int reject_impl(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt,
                 LAUNCH_STAT(32);
         }
 #undef LAUNCH_STAT
-        double *stat_d = ctx->result_d + 20;  // [mean, variance, total pair count]
-        double *xbuf_d = ctx->result_d;       // [17] exchange buffer: {sum, count, 0...}
-        hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const double *)d_d, P,
-                           (const double *)nullptr, 1, xbuf_d);
-        if (reduce) reduce_rc = reduce(reduce_user, xbuf_d);  // sum over ranks of {sum d, P} (enqueued on the stream)
+        double *stat_d = ctx->result_d + 20;  // [mean, variance, total pair count, failed ranks]
+        double *xbuf_d = ctx->result_d;       // [17] exchange buffer: {sum, count, failed, 0...}
+        hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const double *)d_d, Pw,
+                           (const double *)nullptr, 1, local_fail ? 1 : 0, xbuf_d);
+        if (reduce) reduce_rc = reduce(reduce_user, xbuf_d);  // sum over ranks of {sum d, P, failed} (enqueued on the stream)
         hipLaunchKernelGGL(finish_stat_kernel, dim3(1), dim3(1), 0, ctx->stream, (const double *)xbuf_d,
-                           (const double *)(xbuf_d + 1), stat_d, 0, stat_d + 2);
-        hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const double *)d_d, P,
-                           (const double *)stat_d, 0, xbuf_d);
-        if (reduce && reduce_rc == PCR_OK) reduce_rc = reduce(reduce_user, xbuf_d);  // sum over ranks of sum (d - mean)^2
+                           (const double *)(xbuf_d + 1), stat_d, 0, stat_d + 2, stat_d + 3);
+        hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const double *)d_d, Pw,
+                           (const double *)stat_d, 0, (local_fail || reduce_rc != PCR_OK) ? 1 : 0, xbuf_d);
+        if (reduce) {  // sum over ranks of sum (d - mean)^2 -- entered even if the first exchange failed HERE: the other
+                       // ranks are on their way into it
+            const int rc2 = reduce(reduce_user, xbuf_d);
+            if (reduce_rc == PCR_OK) reduce_rc = rc2;
+        }
         hipLaunchKernelGGL(finish_stat_kernel, dim3(1), dim3(1), 0, ctx->stream, (const double *)xbuf_d,
-                           (const double *)(stat_d + 2), stat_d, 1, (double *)nullptr);
-        if (P)
-            hipLaunchKernelGGL(reject_mask_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const double *)d_d, P,
+                           (const double *)(stat_d + 2), stat_d, 1, (double *)nullptr, stat_d + 3);
+        if (Pw)
+            hipLaunchKernelGGL(reject_mask_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const double *)d_d, Pw,
                                (const double *)stat_d, cdf, k_d);
         e = hipGetLastError();
-        if (e == hipSuccess && P) e = hipMemcpyAsync(out_keep, k_d, P, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess && out_d && P) e = hipMemcpyAsync(out_d, d_d, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && Pw) e = hipMemcpyAsync(out_keep, k_d, Pw, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && out_d && Pw) e = hipMemcpyAsync(out_d, d_d, sizeof(double) * Pw, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess)
-            e = hipMemcpyAsync(ctx->result_h + 20, stat_d, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream);
+            e = hipMemcpyAsync(ctx->result_h + 20, stat_d, sizeof(double) * 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e == hipSuccess && out_stat) {
             out_stat[0] = ctx->result_h[20];
@@ -268,10 +290,20 @@ static int reject_impl(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt,
     if (pq_d) hipFree(pq_d);
     if (d_d) hipFree(d_d);
     if (k_d) hipFree(k_d);
+    if (local_fail) PCR_HIP(local_err);
     PCR_HIP(e);
     if (reduce_rc != PCR_OK) {
         set_last_error("pcr_reject_centroid_dist_sharded: the reduction hook failed (%d)", reduce_rc);
         return reduce_rc < 0 ? reduce_rc : PCR_E_INVALID;
+    }
+    if (ctx->result_h[23] > 0.0) {
+        set_last_error("pcr_reject_centroid_dist_sharded: %g rank(s) could not do their share (allocation, copy or exchange "
+                       "failed there); every rank returns this error", ctx->result_h[23]);
+        return PCR_E_HIP;
+    }
+    if (!(ctx->result_h[22] >= 1.0)) {
+        set_last_error("pcr_reject_centroid_dist: no pair on any rank (the reference asserts, RejectionCentroidDist.cpp:27)");
+        return PCR_E_INVALID;
     }
     return PCR_OK;
 }

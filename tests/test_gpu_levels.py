@@ -227,6 +227,19 @@ def test_sharded_centroid_rejection_equals_whole(pcr, oracle):
     a, b = run([(0, len(pp)), (0, 0)])   # a rank without pairs still takes part in both reductions
     assert (a["keep"] == whole["keep"]).all() and a["mean"] == whole["mean"] and a["sigma"] == whole["sigma"]
     assert b["kept"] == 0 and b["mean"] == whole["mean"]
+    # a hook that FAILS on its first call is still entered a second time (the other ranks are already on their way into
+    # the second exchange and would wait there for ever), and the call reports the failure
+    seen = []
+
+    def failing(ptr):
+        seen.append(ptr)
+        return -2 if len(seen) == 1 else 0
+    with pytest.raises(pcr.PcrError):
+        pcr.reject_centroid_dist(ctxs[0], six, tix, pp[:100], pq[:100], msn=25, msd=8.0, cdf=1.0, reduce=failing)
+    assert len(seen) == 2
+    # no pair on ANY rank: an error, not a division by zero
+    with pytest.raises(pcr.PcrError):
+        pcr.reject_centroid_dist(ctxs[0], six, tix, pp[:0], pq[:0], msn=25, msd=8.0, cdf=1.0, reduce=lambda ptr: 0)
     try:
         comm = pcr.Comm(ctxs[0], 0, 1, pcr.Comm.unique_id())
     except pcr.PcrError:

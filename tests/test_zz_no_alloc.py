@@ -90,3 +90,54 @@ def test_noalloc_step_rejects_sizes_beyond_its_scratch(pcr, ctx):
         got.append(part.cpu().numpy().copy())
     assert (got[0] == got[1]).all() and got[0][0] == pcr.NOALLOC_MAX_SAMPLES  # every point is its own nearest neighbour
     six.close()
+
+
+def test_noalloc_step_runs_under_stream_capture_and_clears_stale_tickets(pcr):
+    """The proof that the call allocates nothing: it is captured into a HIP graph on the context's stream, in GLOBAL
+    capture mode, where hipMalloc/hipFree (from any thread) are errors that invalidate the capture -- a capture that
+    ends well and a replay that reproduces the plain entry point's results bit for bit is that proof.  Before it, the
+    fixed scratch's tickets are deliberately left NON-ZERO (what a launch that died mid-fold would leave): the entry
+    point clears them itself, every call, so later calls are not poisoned for the life of the process."""
+    from pointcloudregistration_amd import synth
+    stream = torch.cuda.Stream()
+    ctx = pcr.Context(0, stream=stream)
+    n = 50000
+    src, tgt, Rm, t = synth.registration_pair(n, n, 1234)
+    six = pcr.Index(ctx, pcr.Cloud(ctx, src), kind=pcr.INDEX_GRID)
+    tix = pcr.Index(ctx, pcr.Cloud(ctx, tgt), kind=pcr.INDEX_GRID)
+    U = tix.unique_sq_dist()
+    R, T = synth.coarse_initial_transform(Rm, t, n)
+    dev = f"cuda:{ctx.device}"
+
+    def buffers():
+        return (torch.full((17,), float("nan"), dtype=torch.float64, device=dev),
+                torch.full((n,), 0x7fffffff, dtype=torch.int32, device=dev),
+                torch.full((n,), 0x7fffffff, dtype=torch.int32, device=dev),
+                torch.full((n,), 7, dtype=torch.uint8, device=dev))
+    want = buffers()
+    got = buffers()
+    torch.cuda.synchronize()
+    pcr.icp_step_d(ctx, six, tix, R, T, 4, U * 36.0, U * 4.0, want[0], exact=True, out_fwd_t=want[1], out_rev_t=want[2],
+                   out_keep_t=want[3])
+    ctx.synchronize()
+    # poison the tickets of the fixed scratch, as an aborted launch would
+    assert pcr.lib().pcr_noalloc_debug_poison_tickets(ctx.h) == 0
+    ctx.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream, capture_error_mode="global"):
+        pcr.icp_step_d(ctx, six, tix, R, T, 4, U * 36.0, U * 4.0, got[0], exact=True, out_fwd_t=got[1], out_rev_t=got[2],
+                       out_keep_t=got[3], noalloc=True)
+    torch.cuda.synchronize()
+    assert torch.isnan(got[0]).all() and (got[3] == 7).all()   # captured, not run
+    for _ in range(2):                                          # replayed twice: the second run starts from the first's tickets
+        got[0].fill_(float("nan"))
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert want[0][0].item() > 1000
+        for a, b, what in zip(want, got, ("partials", "fwd", "rev", "keep")):
+            assert torch.equal(a, b), what
+    del graph
+    six.close()
+    tix.close()
+    ctx.close()
