@@ -79,6 +79,9 @@ PCR_HD inline bool make_dyn(const double *R, const double *T, const double *c_sr
 }
 
 __global__ void set_dyn_kernel(StepDyn value, StepDyn *dst) { *dst = value; }
+__global__ void __launch_bounds__(256) fill_u32_kernel(uint32_t *dst, uint32_t n, uint32_t value) {
+    for (uint32_t i = threadIdx.x; i < n; i += 256u) dst[i] = value;
+}
 
 
 struct FitDev;
@@ -1322,9 +1325,9 @@ int pcr_icp_step_noalloc_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *
     PCR_HIP(hipSetDevice(ctx->device));
     // The fold's tickets must start at zero.  Every launch that completes leaves them so -- but the array lives as long
     // as the process, and a launch that died half-way (or two calls that overlapped against the documented rule) would
-    // otherwise poison every later call on this GPU: clear them here, stream-ordered, every call.  A memset node
-    // allocates nothing and is legal under stream capture.
-    PCR_HIP(hipMemsetAsync(S->tickets, 0, sizeof S->tickets, ctx->stream));
+    // otherwise poison every later call on this GPU: clear them here, stream-ordered, every call -- with a tiny kernel
+    // (allocates nothing, and is an ordinary kernel node under stream capture).
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(1), dim3(256), 0, ctx->stream, S->tickets, (uint32_t)(sizeof S->tickets / 4), 0u);
     return step_enqueue(ctx, src, tgt, sample_idx_d, sample_begin, m, R, T, k, thr_fwd_sq, thr_rev_sq, flags, partials_d,
                         out_fwd_d, out_rev_d, out_keep_d, &S->step, S->group_partials, S->tickets, S->block_partials,
                         "pcr_icp_step_noalloc_d");
@@ -1336,7 +1339,8 @@ int pcr_noalloc_debug_poison_tickets(pcr_ctx *ctx) {
     NoAllocScratch *S = noalloc_scratch_of(ctx->device);
     PCR_REQUIRE(S, "pcr_noalloc_debug_poison_tickets: no scratch on device %d", ctx->device);
     PCR_HIP(hipSetDevice(ctx->device));
-    PCR_HIP(hipMemsetAsync(S->tickets, 0x01, sizeof S->tickets, ctx->stream));
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(1), dim3(256), 0, ctx->stream, S->tickets, (uint32_t)(sizeof S->tickets / 4), 0x01010101u);
+    PCR_HIP(hipGetLastError());
     return PCR_OK;
 }
 

@@ -120,7 +120,15 @@ def test_noalloc_step_runs_under_stream_capture_and_clears_stale_tickets(pcr):
     pcr.icp_step_d(ctx, six, tix, R, T, 4, U * 36.0, U * 4.0, want[0], exact=True, out_fwd_t=want[1], out_rev_t=want[2],
                    out_keep_t=want[3])
     ctx.synchronize()
-    # poison the tickets of the fixed scratch, as an aborted launch would
+    # poison the tickets of the fixed scratch, as an aborted launch would; a plain (uncaptured) call first
+    assert pcr.lib().pcr_noalloc_debug_poison_tickets(ctx.h) == 0
+    pcr.icp_step_d(ctx, six, tix, R, T, 4, U * 36.0, U * 4.0, got[0], exact=True, out_fwd_t=got[1], out_rev_t=got[2],
+                   out_keep_t=got[3], noalloc=True)
+    ctx.synchronize()
+    for a, b, what in zip(want, got, ("partials", "fwd", "rev", "keep")):
+        assert torch.equal(a, b), ("uncaptured call after poisoned tickets", what)
+    got = buffers()
+    torch.cuda.synchronize()
     assert pcr.lib().pcr_noalloc_debug_poison_tickets(ctx.h) == 0
     ctx.synchronize()
     graph = torch.cuda.CUDAGraph()
@@ -135,8 +143,8 @@ def test_noalloc_step_runs_under_stream_capture_and_clears_stale_tickets(pcr):
         graph.replay()
         torch.cuda.synchronize()
         assert want[0][0].item() > 1000
-        for a, b, what in zip(want, got, ("partials", "fwd", "rev", "keep")):
-            assert torch.equal(a, b), what
+        for a, b, what in zip(reversed(want), reversed(got), ("keep", "rev", "fwd", "partials")):
+            assert torch.equal(a, b), ("graph replay", what)
     del graph
     six.close()
     tix.close()
