@@ -95,6 +95,110 @@ def cpu_baseline(src, tgt, R0, T0, k, sdft, ndft, budget_s=25.0):
             "seconds_per_iteration": s_multi, "single_thread_seconds_per_iteration": s_single}
 
 
+def extra_c5(capi, synth, device, n=16_000_000, k=4, launches=5):
+    """BASELINE config C5 in the driver's line: LiDAR-like n x n pair (density ~ 1/r^2 from the sensor, 30 % of the source
+    replaced by uniform outliers), nested-level grid indices, ONE ICRP step over all n samples per launch (production
+    mode: gate early-out, no index outputs).  Kernel time per launch by HIP events on the context's stream; inputs and
+    indices resident.  Same algorithmic bytes per sample as the headline (56 + 24 K)."""
+    t0 = time.perf_counter()
+    src, tgt, Rm, t = synth.lidar_pair(n, 516, outlier_frac=0.3)
+    gen_s = time.perf_counter() - t0
+    ctx = capi.Context(device)
+    t0 = time.perf_counter()
+    six, tix = capi.Index(ctx, capi.Cloud(ctx, src)), capi.Index(ctx, capi.Cloud(ctx, tgt))
+    ctx.synchronize()
+    build_s = time.perf_counter() - t0
+    U = tix.unique_sq_dist()
+    R, T = synth.colmajor(Rm), t
+    capi.icp_step(ctx, six, tix, R, T, k, U * 36.0, U * 4.0, exact=False, want_outputs=False)  # warm-up
+    ctx.set_profiling(True, classes=[1])
+    ctx.read_kernel_times()
+    for _ in range(launches):
+        out = capi.icp_step(ctx, six, tix, R, T, k, U * 36.0, U * 4.0, exact=False, want_outputs=False)
+    ms, cnt = ctx.read_kernel_times()["step"]
+    ctx.set_profiling(False)
+    step_ms = ms / max(cnt, 1)
+    si, ti = six.info(), tix.info()
+    by = algorithmic_bytes_per_sample(k) * n
+    res = {"workload": f"C5 synthetic LiDAR-like {n}x{n} points, 30% outliers in the source, K={k}, one ICRP step over all "
+                       f"samples per launch (seed 516)",
+           "step_ms": step_ms, "launches": cnt, "samples_per_s": n / (step_ms * 1e-3), "kernel": capi.last_step_kernel(),
+           "kept_pairs": float(out["partials"][0]),
+           "roofline": {"bound": "hbm", "achieved": by / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": by / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": by},
+           "index_build_s_both_clouds": build_s, "synthesis_s": gen_s,
+           "src_index": {kk: si[kk] for kk in ("levels", "cells", "occupied_cells", "device_bytes")},
+           "tgt_index": {kk: ti[kk] for kk in ("levels", "cells", "occupied_cells", "device_bytes")}}
+    six.close()
+    tix.close()
+    ctx.close()
+    return res
+
+
+def extra_c4(capi, synth, device, reps=3):
+    """BASELINE config C4 in the driver's line: a scan set registered pair by pair (14 fits over 15 synthetic partial
+    scans of 50-80 k points; the Happy Buddha scans are not in the reference tree), RegCfg criteria, up to 30 iterations
+    each -- fits per second one after the other against ONE launch per iteration for all of them (pcr_fit_batch); both
+    must give identical transforms.  Index builds outside the timed regions."""
+    rng = np.random.default_rng(7)
+    sizes = rng.integers(50000, 80001, 15)
+    scans = [synth.scan_sequence(i + 1, int(nn), 9000)[0][i] for i, nn in enumerate(sizes)]
+    pairs = [(scans[i + 1], scans[i]) for i in range(len(scans) - 1)]
+    conv = capi.ConvergenceParams.regcfg(30)
+    eye, zero = np.eye(3).reshape(9), np.zeros(3)
+    ctx = capi.Context(device)
+    t0 = time.perf_counter()
+    fits, keep = [], []
+    for sp, tp in pairs:
+        six, tix = capi.Index(ctx, capi.Cloud(ctx, sp)), capi.Index(ctx, capi.Cloud(ctx, tp))
+        U = tix.unique_sq_dist()
+        keep.append((six, tix))
+        fits.append(capi.Fit(ctx, six, tix, 4, U * 36.0, U * 4.0, conv=conv, unique_sq_dist=U, traj_cap=32))
+    ctx.synchronize()
+    build_s = time.perf_counter() - t0
+    batch = capi.FitBatch(ctx, fits)
+
+    def timed(fn):
+        best = None
+        for _ in range(reps):
+            for f in fits:
+                f.reset(eye, zero)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            ctx.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best, [f.read() for f in fits]
+
+    def sequential():
+        for f in fits:
+            for _ in range(30):
+                f.iterate()
+
+    def one_launch():
+        for _ in range(30):
+            batch.iterate()
+    t_seq, r_seq = timed(sequential)
+    t_bat, r_bat = timed(one_launch)
+    same = all(a["iterations"] == b["iterations"] and a["state"] == b["state"] and (a["R"] == b["R"]).all() and
+               (a["T"] == b["T"]).all() for a, b in zip(r_seq, r_bat))
+    res = {"workload": f"C4 stand-in: {len(pairs)} pairwise fits over 15 synthetic partial scans of {int(sizes.min())}-"
+                       f"{int(sizes.max())} points, K=4, RegCfg criteria, up to 30 iterations each",
+           "fits_per_s": {"sequential": len(pairs) / t_seq, "one_launch_per_iteration": len(pairs) / t_bat},
+           "ms_total": {"sequential": t_seq * 1e3, "one_launch_per_iteration": t_bat * 1e3},
+           "iterations_per_fit": [r["iterations"] for r in r_seq], "batch_equals_sequential_bit_for_bit": bool(same),
+           "index_build_s_all_pairs": build_s}
+    batch.close()
+    for f in fits:
+        f.close()
+    for a, b in keep:
+        a.close()
+        b.close()
+    ctx.close()
+    return res
+
+
 def spawn_ranks(n):
     import socket
     import subprocess
@@ -128,6 +232,7 @@ def main():
                          "(a power-managed device needs ~0.1 s of load: 6 550 it/s after 10 iterations, 6 800 after 300)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-knn", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the C5 (16 M LiDAR step) and C4 (batch of small fits) legs")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher: be the launcher.  N fresh child processes, one per GPU, started
@@ -158,6 +263,10 @@ def main():
         local_rank = 0
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ.get("PCR_BENCH_DUMP_AFTER", "240")), exit=True)  # a rehearsal that stalls says where
+        if os.environ.get("PCR_BENCH_THREAD_DUMP_AFTER"):  # ... and what every OS thread was blocked in (tools/thread_dump.py)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import thread_dump
+            thread_dump.arm(float(os.environ["PCR_BENCH_THREAD_DUMP_AFTER"]))
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -249,6 +358,8 @@ def main():
                     torch.cuda.synchronize()  # gloo stages through the host: tell a stalled kernel from a stalled exchange
                 if comm is not None:
                     comm.allreduce_partials(part_ptr)
+                elif rehearse and os.environ.get("PCR_BENCH_GLOO_DEVICE") == "1":  # (diagnostic: the route that stalled)
+                    dist.all_reduce(part_t)
                 elif rehearse:  # gloo on a HOST tensor: its device-tensor path stalls now and then when two ranks share a GPU
                     host = part_t.cpu()
                     dist.all_reduce(host)
@@ -419,6 +530,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(src, tgt, R0, T0, k, sdft, ndft)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        if world == 1 and not args.no_extra and not force_dist and emulate <= 1:
+            # the other BASELINE configurations that fit one GPU, after the headline (extra keys; `value` is C3's)
+            for key, fn in (("c5", extra_c5), ("c4", extra_c4)):
+                try:
+                    out[key] = fn(capi, synth, local_rank)
+                except Exception as e:  # an extra leg must never cost the headline line
+                    out[key] = {"error": f"{type(e).__name__}: {e}"}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if comm is not None:

@@ -151,9 +151,9 @@ struct StageClock {
 //              caller then need not gather it again -- two dependent round trips saved per search
 // Returns false when this search cannot vouch for the result (not settled within ring 1, a cell row too long for the
 // payload, a query far outside the grid, an unresolved near-tie): the caller runs lane_search instead.
-// TRIES, U: see phase 2 (U: shadow records per trip).  GV, RG: GridView and Rigid in whatever address space the caller keeps them (the step kernel: the constant one,
+// TRIES, U: see phase 2 (U: shadow records per trip).  RS: lanes per row of `rowtab` (ring1_pruned).  GV, RG: GridView and Rigid in whatever address space the caller keeps them (the step kernel: the constant one,
 // so that every field is a scalar load at its point of use).
-template <int KC, bool XF, bool SEEDED, int TRIES = 1, int U = PCR_FAST_U, class GV, class RG>
+template <int KC, bool XF, bool SEEDED, int TRIES = 1, int U = PCR_FAST_U, int RS = PCR_ROW_STRIDE, class GV, class RG>
 __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ exact_pts, double qx, double qy,
                                            double qz, double sx, double sy, double sz, double max_d2, double bound_d2,
                                            double bound_scale, double extra_margin, uint32_t delta, int k,
@@ -238,7 +238,7 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
             const uint32_t tot = p3 - p0;
             ok &= !(open & (tot > 255u));  // the payload holds 8 bits of offset: a longer row is the fp64 walk's business
             if (open & (tot != 0u)) {
-                rowtab[cnt * PCR_ROW_STRIDE] = make_uint2(p0, (p1 - p0) | ((p2 - p1) << 8) | ((p3 - p2) << 16) | (rowk & 0xFF000000u));
+                rowtab[cnt * RS] = make_uint2(p0, (p1 - p0) | ((p2 - p1) << 8) | ((p3 - p2) << 16) | (rowk & 0xFF000000u));
                 ++cnt;
             }
         }
@@ -266,7 +266,7 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
 #pragma unroll
         for (int tries = 0; tries < TRIES; ++tries) {
             if (want) {
-                const uint2 row = rowtab[ri * PCR_ROW_STRIDE];
+                const uint2 row = rowtab[ri * RS];
                 const uint32_t n0 = row.y & 255u, n1 = (row.y >> 8) & 255u, n2 = (row.y >> 16) & 255u, rk = row.y & 0xFF000000u;
                 const uint32_t UB = sat_add(min(T.t[KC - 1], bound_k) | ~KEY_DIST_MASK, delta);
                 const bool trim_lo = sat_add(rk, gxl_k) > UB, trim_hi = sat_add(rk, gxh_k) > UB;
@@ -319,7 +319,7 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
         d = max_d2;
         ci = PCR_NO_INDEX;
         if (key != KEY_SENTINEL) {
-            const uint32_t pos = rowtab[((key >> 8) & 15u) * PCR_ROW_STRIDE].x + (key & 255u);
+            const uint32_t pos = rowtab[((key >> 8) & 15u) * RS].x + (key & 255u);
             const Pt4 cnd = exact_pts[pos];
             const double dd = cand_d2<XF, RG>(xf, qx, qy, qz, cnd);
             if (dd < max_d2) {
@@ -347,7 +347,7 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
 #pragma unroll
         for (int j = 0; j < KC; ++j) {
             const uint32_t key = T.t[j];
-            const uint32_t base = rowtab[((key >> 8) & 15u) * PCR_ROW_STRIDE].x;
+            const uint32_t base = rowtab[((key >> 8) & 15u) * RS].x;
             cpos[j] = key != KEY_SENTINEL ? base + (key & 255u) : 0u;
         }
 #pragma unroll

@@ -501,8 +501,10 @@ __device__ __forceinline__ int grid_search(const GridView &g, const Pt4 *__restr
 // One loop with a straight-line body (open next row | evaluate up to PCR_WALK_UNROLL candidates).
 // rowtab: this lane's column, row r at rowtab[r * PCR_ROW_STRIDE] (consecutive lanes, 8 bytes: conflict-free).
 // Returns true if the K-th best is provably final (or the grid is exhausted).
+// RS: lanes per row of the table the caller handed in -- 256 in the 256-lane kernels, 64 in the filtered step kernel,
+// whose blocks are single waves.
 #define PCR_ROW_STRIDE 256
-template <int KC, bool XF = false>
+template <int KC, bool XF = false, int RS = PCR_ROW_STRIDE>
 __device__ __forceinline__ bool ring1_pruned(const GridView &g, const Pt4 *__restrict__ cand, double qx, double qy,
                                              double qz, double sx, double sy, double sz, double max_d2,
                                              double bound_scale, double extra_margin, TopK<KC> &top, uint2 *rowtab,
@@ -564,7 +566,7 @@ __device__ __forceinline__ bool ring1_pruned(const GridView &g, const Pt4 *__res
             const double gz2 = DZ[r] < 0 ? gzl : (DZ[r] > 0 ? gzh : 0.0);
             const bool inside = (ry >= 0) & (ry < gy) & (rz >= 0) & (rz < gz);
             const float f = inside ? __double2float_rd(gy2 + gz2) : __builtin_huge_valf();
-            rowtab[r * PCR_ROW_STRIDE] = make_uint2(__float_as_uint(f), cbase + (uint32_t)(DY[r] * gx + DZ[r] * zstep));
+            rowtab[r * RS] = make_uint2(__float_as_uint(f), cbase + (uint32_t)(DY[r] * gx + DZ[r] * zstep));
         }
     }
     const bool has_xl = cx > 0, has_xh = cx < gx - 1;
@@ -575,7 +577,7 @@ __device__ __forceinline__ bool ring1_pruned(const GridView &g, const Pt4 *__res
         DIAG_ADD(8 * (KC == 1) + 0, 1);                                        // wave trips
         DIAG_ADD(8 * (KC == 1) + 1, __any((p >= e) & (ri < 9)) ? 1 : 0);       // wave-level open executions
         if ((p >= e) & (ri < 9)) {
-            const uint2 row = rowtab[ri * PCR_ROW_STRIDE];
+            const uint2 row = rowtab[ri * RS];
             ++ri;
             const double gyz = (double)__uint_as_float(row.x);
             // rows outside the grid carry +inf; the explicit test matters while wd itself is still +inf
@@ -617,13 +619,13 @@ __device__ __forceinline__ bool ring1_pruned(const GridView &g, const Pt4 *__res
 }
 
 // The per-lane search the kernels use: pruned ring 1, then (rarely) the generic shells from ring 2 on.
-template <int KC, bool XF = false>
+template <int KC, bool XF = false, int RS = PCR_ROW_STRIDE>
 __device__ __forceinline__ void lane_search(const GridView &g, const Pt4 *__restrict__ cand, double qx, double qy,
                                             double qz, double sx, double sy, double sz, double max_d2,
                                             double bound_scale, double extra_margin, TopK<KC> &top,
                                             uint2 *rowtab, const Rigid *xf = nullptr) {
     DIAG_LANE_ADD(8 * (KC == 1) + 5, 1);  // lane searches
-    const bool fin1 = ring1_pruned<KC, XF>(g, cand, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, rowtab, xf);
+    const bool fin1 = ring1_pruned<KC, XF, RS>(g, cand, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, rowtab, xf);
     if (!fin1)
         grid_search<KC, false, XF>(g, cand, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, 2, xf);
 }

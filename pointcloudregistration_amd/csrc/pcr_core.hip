@@ -714,6 +714,8 @@ int pcr_ctx_create(int device, pcr_ctx **out) {
             PCR_HIP(e);
         }
     }
+    c->cu_count = 0;
+    (void)hipDeviceGetAttribute(&c->cu_count, hipDeviceAttributeMultiprocessorCount, device);
     hipError_t e = hipMalloc(&c->result_d, sizeof(double) * 32);
     if (e == hipSuccess) e = hipHostMalloc(&c->result_h, sizeof(double) * 32, hipHostMallocDefault);
     if (e != hipSuccess) {

@@ -96,14 +96,14 @@ struct StepArgs {
     int k;
     double thr_fwd, thr_rev;
     uint32_t exact;  // PCR_STEP_EXACT_INDICES
-    double *block_partials;  // [17][gridDim.x]
+    double *tile_partials;  // [17][ntiles], ntiles = ceil(m / 64): one partial per column and wave (wave_reduce17)
     // device-resident loop only (else NULL): per sample slot t, the forward search's exact K-th squared distance of the
     // previous iteration, rounded up to float (+inf: none) -- read as a bound, overwritten with this iteration's
     float *dk_io;
-    // In-kernel fold (filtered kernel; NULL tickets: fold_partials_kernel follows instead).  Blocks are grouped by 64;
-    // the block that finishes a group last folds the group's partials, the block that finishes the last group folds
-    // the groups into partials_out -- fixed grouping, fixed order: bitwise reproducible -- and sets every counter back
-    // to zero for the next launch.  fit_inline (device-resident loop on one GPU): that same block then runs the solve.
+    // In-kernel fold (NULL tickets: fold_partials_kernel follows instead).  Tiles are grouped by 64; the wave that hands
+    // in a group's last tile folds the group's partials, the wave that finishes the last group folds the groups into
+    // partials_out -- fixed grouping, fixed order: bitwise reproducible -- and sets every counter back to zero for the
+    // next launch.  fit_inline (device-resident loop on one GPU): that same wave then runs the solve.
     uint32_t *tickets;       // [1 + ngroups], zero between launches
     double *group_partials;  // [17][ngroups]
     double *partials_out;    // [17]
@@ -163,45 +163,58 @@ __device__ __forceinline__ double ld_agent(const double *p) {
 // tests/test_isa_fold_order.py checks the shipped code object for it.
 __device__ __forceinline__ void wait_stores_acked() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// 17 per-lane values -> one value per block and column, stored column-major [17][nblocks] so that the fold
-// reads coalesced.  Through LDS, not shuffles: every lane parks its 17 values (17 conflict-free writes), then 16 lanes
-// per column add 16 values each and a 4-step shuffle tree finishes the column -- about 65 instructions per wave where
-// a 6-step shuffle tree per value costs over 300 (8 % of the filtered step kernel).  Fixed order: reproducible bit for
-// bit, and the same in every kernel that ends this way.
-//   lds: REDUCE17_LDS_BYTES of shared memory that the block no longer needs for anything else (the kernels hand over
-//   the buffer their search used: the barrier at the top waits for every wave to be done with it).
-constexpr int REDUCE17_STRIDE = 256 + 16;  // doubles per column: columns 16 lanes apart land on different banks
-constexpr int REDUCE17_LDS_BYTES = 17 * REDUCE17_STRIDE * 8;
-__device__ __forceinline__ void block_reduce17(double (&v)[17], double *__restrict__ lds, double *__restrict__ out,
-                                               uint32_t block, uint32_t nblocks) {
-    const uint32_t tid = threadIdx.x;
-    __syncthreads();
+// ---- the 17 sums: per TILE (the 64 samples of one wave), per GROUP of 64 tiles, total -----------------------------
+// Every step kernel ends the same way, so that their sums are bit-identical to each other: a wave reduces its 64 lanes'
+// 17 values to one partial per column (wave_reduce17: fixed order), stores it at [column][tile]; the wave that hands in
+// the last tile of a group of 64 folds the group (wave_fold17), the wave that hands in the last group folds the groups
+// into the 17 sums -- fixed grouping, fixed order: bitwise reproducible run to run -- and, in a device-resident fit on
+// one GPU, runs the solve.  The unit is the WAVE, not the block: a wave of the filtered kernel (64-lane blocks) frees
+// its slot when IT is done, not when the slowest of four is (round 2: 6 000 of a block's 61 500 cycles).
+constexpr int WR_STRIDE = 68;  // doubles per column of a wave's scratch: 8 columns x 4 parts of a half-wave read land on 32 distinct bank pairs
+constexpr int WAVE_LDS_BYTES = 17 * WR_STRIDE * 8;      // 9 248
+constexpr int REDUCE17_LDS_BYTES = 4 * WAVE_LDS_BYTES;  // a 256-lane block: one slice per wave (36 992)
+
+// LDS written by some lanes of a wave and read by others of the SAME wave: the hardware executes a wave's LDS
+// instructions in order; this only keeps the compiler from reordering them.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 17 per-lane values -> one value per column, through the wave's own LDS slice, not shuffles: every lane parks its 17
+// values (17 conflict-free writes), four lanes per column add 16 values each and a 2-step shuffle finishes columns
+// 0..15; column 16 takes 16 lanes x 4 values and a 4-step shuffle.  On return lane 4c holds column c (c < 16) in s,
+// lane 0 holds column 16 in s16.  Fixed order: reproducible bit for bit.
+//   lds: WAVE_LDS_BYTES that the WAVE no longer needs for anything else (it hands over its row table)
+__device__ __forceinline__ void wave_reduce17(const double (&v)[17], double *__restrict__ lds, double &s, double &s16) {
+    const uint32_t lane = threadIdx.x & 63u;
+    wave_lds_sync();
 #pragma unroll
-    for (int j = 0; j < 17; ++j) lds[j * REDUCE17_STRIDE + tid] = v[j];
-    __syncthreads();
-    const uint32_t col = tid >> 4, part = tid & 15u;
-    double s = 0.0;
+    for (int j = 0; j < 17; ++j) lds[j * WR_STRIDE + lane] = v[j];
+    wave_lds_sync();
+    const uint32_t col = lane >> 2, part = lane & 3u;
+    s = 0.0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s += lds[col * REDUCE17_STRIDE + i * 16 + part];
-    s += __shfl_xor(s, 8, 64);
-    s += __shfl_xor(s, 4, 64);
+    for (int i = 0; i < 16; ++i) s += lds[col * WR_STRIDE + i * 4 + part];
     s += __shfl_xor(s, 2, 64);
     s += __shfl_xor(s, 1, 64);
-    // device-scope (write-through) stores: the in-kernel fold of another block, on another XCD, reads them
-    if (part == 0u) st_agent(&out[(size_t)col * nblocks + block], s);
-    if (tid < 64u) {  // the seventeenth column: the first wave once more (16 of its lanes hold real data)
-        double s16 = 0.0;
-        if (tid < 16u) {
+    s16 = 0.0;
+    if (lane < 16u) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s16 += lds[16 * REDUCE17_STRIDE + i * 16 + tid];
-        }
-        s16 += __shfl_xor(s16, 8, 64);
-        s16 += __shfl_xor(s16, 4, 64);
-        s16 += __shfl_xor(s16, 2, 64);
-        s16 += __shfl_xor(s16, 1, 64);
-        if (tid == 0u) st_agent(&out[(size_t)16 * nblocks + block], s16);
+        for (int i = 0; i < 4; ++i) s16 += lds[16 * WR_STRIDE + i * 16 + lane];
     }
-    wait_stores_acked();  // before any barrier behind which a ticket is drawn (fold_in_kernel)
+    s16 += __shfl_xor(s16, 8, 64);
+    s16 += __shfl_xor(s16, 4, 64);
+    s16 += __shfl_xor(s16, 2, 64);
+    s16 += __shfl_xor(s16, 1, 64);
+    wave_lds_sync();  // (the slice may be written again at once: a fold right after a tile)
+}
+// ... stored at out[column * stride + at]: device-scope (write-through) stores -- the fold of a wave on another XCD reads them
+__device__ __forceinline__ void store17(double s, double s16, double *__restrict__ out, size_t stride, size_t at) {
+    const uint32_t lane = threadIdx.x & 63u;
+    if ((lane & 3u) == 0u) st_agent(&out[(size_t)(lane >> 2) * stride + at], s);
+    if (lane == 0u) st_agent(&out[(size_t)16 * stride + at], s16);
 }
 
 template <class DY>
@@ -232,65 +245,96 @@ __device__ __forceinline__ void accumulate(double (&acc)[17], bool keep, double 
 // one thread of the solve (defined with the device-resident loop below)
 __device__ void fit_solve_body(FitDev *F, const double *partials, double *traj);
 
-// 17 columns x `count` values (column j at x + j * stride) -> out[j * out_stride]: eight threads per column, each a
-// fixed strided share, then a fixed shuffle tree.  Called by whole blocks; threads 0..135 work.
-__device__ __forceinline__ void fold17(const double *x, size_t stride, uint32_t count, double *out, size_t out_stride) {
-    const uint32_t tid = threadIdx.x, col = tid >> 3, sub = tid & 7u;
-    double s = 0.0;
-    if (tid < 136u)
-        for (uint32_t i = sub; i < count; i += 8u) s += ld_agent(&x[(size_t)col * stride + i]);
-    s += __shfl_xor(s, 4, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 1, 64);
-    if (tid < 136u && sub == 0u) st_agent(&out[(size_t)col * out_stride], s);
-    wait_stores_acked();  // the caller's next barrier hands these to another block's fold, or to the solve
+// 17 columns x `count` values (column j at x + j * stride + i) -> out[j * out_stride]: ONE wave; lane l adds the
+// values i = l, l + 64, ... in that order, then wave_reduce17.  Device-scope loads (they miss the XCD's L2 by
+// construction); the caller has made sure the values are there (a ticket).
+__device__ __forceinline__ void wave_fold17(const double *x, size_t stride, uint32_t count, double *__restrict__ lds,
+                                            double *out, size_t out_stride) {
+    const uint32_t lane = threadIdx.x & 63u;
+    double v[17];
+#pragma unroll
+    for (int j = 0; j < 17; ++j) v[j] = 0.0;
+    for (uint32_t i = lane; i < count; i += 64u) {
+#pragma unroll
+        for (int j = 0; j < 17; ++j) v[j] += ld_agent(&x[(size_t)j * stride + i]);
+    }
+    double s, s16;
+    wave_reduce17(v, lds, s, s16);
+    store17(s, s16, out, out_stride, 0);
 }
 
 #ifdef PCR_BLOCK_TIMES
 __device__ unsigned long long g_solve_times[4];  // timing build: last fold's start, solve start, solve end (100 MHz ticks)
 #endif
-// After block_reduce17: the in-kernel fold described at StepArgs::tickets.  Block-uniform control flow throughout.
+// The hand-over.  A wave that has stored tile partials -- and whose storing lanes have waited for memory's
+// acknowledgement (wait_stores_acked) -- draws a ticket of the tiles' group: a device-scope atomic add by lane 0 of as
+// many tiles as it hands in.  The wave that draws the group's last ticket folds the group, draws the launch's ticket
+// and, if that was the last group, folds the groups, sets every counter back to zero for the next launch and runs the
+// solve.  Wave-uniform control flow throughout; no block barrier anywhere in here.
+// (Measured and dropped, round 3: (i) an ARRIVAL ticket drawn before the closing arithmetic plus a fire-and-forget
+// completion count, so that 63 waves of 64 end one round trip earlier -- 141.3 us against 136.2: a device-scope atomic
+// takes longer to come back than the closing arithmetic lasts, and there are twice as many of them; (ii) several tiles
+// per wave, a tile's ticket drawn and redeemed while the wave works on its next tile -- any loop around the tile's body
+// takes the register allocator from 62 spilled registers to 96-147, some inside the candidate loops: 173-192 us.)
+__device__ __forceinline__ uint32_t ticket_draw(uint32_t *tickets, uint32_t g, uint32_t handed_in) {
+    uint32_t old = 0;
+    if ((threadIdx.x & 63u) == 0u)
+        old = __hip_atomic_fetch_add(&tickets[1u + g], handed_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_amdgcn_readfirstlane(old);
+}
 template <class AP>
-__device__ __forceinline__ void fold_in_kernel(AP A, uint32_t lb, uint32_t nb) {
+__device__ __forceinline__ void ticket_redeem(AP A, uint32_t old, uint32_t g, uint32_t handed_in, uint32_t ntiles,
+                                              double *__restrict__ lds) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t ngroups = (ntiles + 63u) >> 6, gsize = min(64u, ntiles - (g << 6));
+    if (old + handed_in != gsize) return;
     uint32_t *tickets = A->tickets;
-    if (!tickets) return;
-    __shared__ uint32_t s_last;
-    const uint32_t ngroups = (nb + 63u) >> 6, g = lb >> 6;
-    // The block's partials are device-scope write-through stores, and every lane that issued one has waited for
-    // memory's acknowledgement (wait_stores_acked, at the end of block_reduce17 / fold17) BEFORE this barrier; thread 0's
-    // ticket, a device-scope atomic, is drawn after it.  A block that sees the last ticket of a group therefore reads
-    // complete partials with device-scope loads (which miss the XCD's L2 by construction) -- no cache-wide fence anywhere.
-    __syncthreads();
-    if (threadIdx.x == 0)
-        s_last = __hip_atomic_fetch_add(&tickets[1u + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-                         min(64u, nb - (g << 6)) - 1u
-                     ? 1u
-                     : 0u;
-    __syncthreads();
-    if (!s_last) return;
-    fold17(A->block_partials + ((size_t)g << 6), nb, min(64u, nb - (g << 6)), A->group_partials + g, ngroups);
-    __syncthreads();
-    if (threadIdx.x == 0)
-        s_last = __hip_atomic_fetch_add(&tickets[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1u ? 1u : 0u;
-    __syncthreads();
-    if (!s_last) return;
+    wave_fold17(A->tile_partials + ((size_t)g << 6), ntiles, gsize, lds, A->group_partials + g, ngroups);
+    wait_stores_acked();
+    uint32_t o2 = 0;
+    if (lane == 0u) o2 = __hip_atomic_fetch_add(&tickets[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__builtin_amdgcn_readfirstlane(o2) != ngroups - 1u) return;
 #ifdef PCR_BLOCK_TIMES
-    if (threadIdx.x == 0) g_solve_times[0] = wall_clock64();
+    if (lane == 0u) g_solve_times[0] = wall_clock64();
 #endif
     double *out = A->partials_out;
-    fold17(A->group_partials, ngroups, ngroups, out, 1);
-    for (uint32_t i = threadIdx.x; i < ngroups + 1u; i += 256u) tickets[i] = 0u;
+    wave_fold17(A->group_partials, ngroups, ngroups, lds, out, 1);
+    for (uint32_t i = lane; i < ngroups + 1u; i += 64u) tickets[i] = 0u;
     FitDev *fit = A->fit_inline;
     if (fit) {
-        __syncthreads();
+        wait_stores_acked();
 #ifdef PCR_BLOCK_TIMES
-        if (threadIdx.x == 0) g_solve_times[1] = wall_clock64();
+        if (lane == 0u) g_solve_times[1] = wall_clock64();
 #endif
-        if (threadIdx.x == 0) fit_solve_body(fit, out, A->fit_traj);
+        if (lane == 0u) fit_solve_body(fit, out, A->fit_traj);
 #ifdef PCR_BLOCK_TIMES
-        if (threadIdx.x == 0) g_solve_times[2] = wall_clock64();
+        if (lane == 0u) g_solve_times[2] = wall_clock64();
 #endif
     }
+}
+
+// The end of a 256-lane block (the fp64 walk, brute force, the normal-aware variant): its four waves are tiles
+// 4 lb .. 4 lb + 3; each reduces and stores its own, wave 0 hands them in together.
+__device__ __forceinline__ void store_block_tiles256(double (&acc)[17], unsigned char *smem, double *tile_partials,
+                                                     uint32_t lb, uint32_t ntiles) {
+    const uint32_t wave = threadIdx.x >> 6, tile = lb * 4u + wave;
+    __syncthreads();  // every wave of the block is done with the search's use of smem (row tables, candidate tiles)
+    if (tile < ntiles) {
+        double s, s16;
+        wave_reduce17(acc, (double *)(smem + wave * WAVE_LDS_BYTES), s, s16);
+        store17(s, s16, tile_partials, ntiles, tile);
+    }
+    wait_stores_acked();  // before the barrier behind which the ticket is drawn
+}
+template <class AP>
+__device__ __forceinline__ void finish_block256(double (&acc)[17], unsigned char *smem, AP A, uint32_t lb, uint32_t ntiles) {
+    store_block_tiles256(acc, smem, A->tile_partials, lb, ntiles);
+    uint32_t *tickets = A->tickets;
+    if (!tickets) return;  // (fold_partials_kernel follows)
+    __syncthreads();
+    if ((threadIdx.x >> 6) != 0u) return;
+    const uint32_t first = lb * 4u, handed_in = min(4u, ntiles - first), g = first >> 6;
+    ticket_redeem(A, ticket_draw(tickets, g, handed_in), g, handed_in, ntiles, (double *)smem);
 }
 
 // MULTI: either index has more than one level (clouds of very uneven density); the single-level instance is the
@@ -398,11 +442,10 @@ __global__ void __launch_bounds__(256, MULTI ? PCR_MULTI_WAVES : PCR_STEP_WAVES)
         if (A.out_rev) A.out_rev[slot] = r;
         if (A.out_keep) A.out_keep[slot] = keep ? 1 : 0;
     }
-    block_reduce17(acc, (double *)smem, A.block_partials, lb, gridDim.x);
 #ifdef PCR_BLOCK_TIMES
     if (threadIdx.x == 0 && lb < 65536u) g_block_times[2 * lb + 1] = wall_clock64();
 #endif
-    fold_in_kernel(&A, lb, gridDim.x);
+    finish_block256(acc, smem, &A, lb, (A.m + 63u) >> 6);
 }
 
 // f4, opt-in (pcr_icp_step_normal_fit): CCorrespondenceEstimationClosestPoints::__insertFitPairs
@@ -496,8 +539,7 @@ __global__ void __launch_bounds__(256, MULTI ? PCR_MULTI_WAVES : PCR_STEP_WAVES)
         if (A.out_fwd) A.out_fwd[slot] = chosen;
         if (A.out_keep) A.out_keep[slot] = keep ? 1 : 0;
     }
-    block_reduce17(acc, (double *)smem, A.block_partials, lb, gridDim.x);
-    fold_in_kernel(&A, lb, gridDim.x);
+    finish_block256(acc, smem, &A, lb, (A.m + 63u) >> 6);
 }
 
 // The same iteration on single-level grids that carry fp32 shadows: both searches go through the filtered walk
@@ -539,7 +581,7 @@ __device__ PCR_FALLBACK_INLINE void fallback_forward(const StepArgs *__restrict_
         const double qmargin = 9.094947017729282e-13 * (fabs(px) + fabs(py) + fabs(pz));
         shells = !ring1_settles(G, px, py, pz, G.margin + qmargin, fwd_scale, top.worst_d(), fmax_d2);
     } else {
-        shells = !ring1_pruned<KC, false>(G, Ap->tgt.all, px, py, pz, px, py, pz, fmax_d2, fwd_scale, 0.0, top, my_rows,
+        shells = !ring1_pruned<KC, false, 64>(G, Ap->tgt.all, px, py, pz, px, py, pz, fmax_d2, fwd_scale, 0.0, top, my_rows,
                                           (const Rigid *)nullptr);
     }
     if (shells) grid_search<KC, false, false>(G, Ap->tgt.all, px, py, pz, px, py, pz, fmax_d2, fwd_scale, 0.0, top, 2);
@@ -553,14 +595,20 @@ __device__ PCR_FALLBACK_INLINE uint32_t fallback_reverse(const StepArgs *__restr
     rt.idx[0] = orig;
     const GridView G = Ap->src.v[0];
     const Rigid M = Ap->dyn->M;
-    lane_search<1, true>(G, Ap->src.all, qx, qy, qz, sx, sy, sz, PCR_INF, rbs, rem_, rt, my_rows, &M);
+    lane_search<1, true, 64>(G, Ap->src.all, qx, qy, qz, sx, sy, sz, PCR_INF, rbs, rem_, rt, my_rows, &M);
     return rt.idx[0];
 }
 
-// lb of nb: the block's place among the blocks of ITS problem (a launch may carry many: icp_step_batch_kernel)
+constexpr int FAST_RS = 64;  // the filtered kernel's blocks are single waves: 64 lanes per row of the LDS row table
+
+// One tile -- 64 samples, one lane each -- of one problem.  smem: the wave's WAVE_LDS_BYTES (row table, then the
+// reduction's scratch).
 template <int KC>
-__device__ __forceinline__ void fast_step_body(const StepArgs *__restrict__ Ap, uint32_t lb, uint32_t nb) {
-    if (Ap->dyn->done) return;  // uniform over the problem's blocks
+__device__ __forceinline__ void fast_tile(const StepArgs *__restrict__ Ap, uint32_t tile, uint32_t ntiles,
+                                          unsigned char *smem) {
+#ifdef PCR_BLOCK_TIMES
+    const uint32_t lb = tile;
+#endif
     FAST_STAMP(0);
 #ifdef PCR_BLOCK_TIMES
     uint32_t ck[6];
@@ -571,9 +619,9 @@ __device__ __forceinline__ void fast_step_body(const StepArgs *__restrict__ Ap, 
 #else
     StageClock *pf = nullptr, *pr = nullptr;
 #endif
-    const uint32_t t = lb * 256u + threadIdx.x;
-    __shared__ __align__(16) unsigned char smem[REDUCE17_LDS_BYTES];  // row tables, then the block reduction's scratch
-    uint2 *my_rows = (uint2 *)smem + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t t = tile * 64u + lane;
+    uint2 *my_rows = (uint2 *)smem + lane;
     uint32_t pos = 0, orig = 0, slot = 0;
     double px = 0, py = 0, pz = 0;
     float dk_prev = __builtin_huge_valf();  // last iteration's K-th squared distance (loaded beside the point: one wait)
@@ -621,9 +669,9 @@ __device__ __forceinline__ void fast_step_body(const StepArgs *__restrict__ Ap, 
             bound_d2 = (double)(s2 * s2) * 1.000001;  // inf stays inf
         }
         if (fin)  // NeighborSet.back() = K-th nearest (:91-92)
-            fwd_done = fast_ring1<KC, false, false>(GT, GT.pts, px, py, pz, px, py, pz, fmax_d2, bound_d2, fwd_scale, 0.0,
-                                                    GT.key_delta, A->k, 0.0, 0u, dF, j, my_rows, (const Rigid *)nullptr, &fx, pf,
-                                                    nullptr, &qpos);
+            fwd_done = fast_ring1<KC, false, false, 1, PCR_FAST_U, FAST_RS>(GT, GT.pts, px, py, pz, px, py, pz, fmax_d2, bound_d2,
+                                                                            fwd_scale, 0.0, GT.key_delta, A->k, 0.0, 0u, dF, j,
+                                                                            my_rows, (const Rigid *)nullptr, &fx, pf, nullptr, &qpos);
         q_known = fin & fwd_done & (qpos != PCR_NO_INDEX);  // the walk hands over q's position with its index
         if (__any(!fwd_done)) {
             if (!fwd_done) fallback_forward<KC>(Ap, px, py, pz, fmax_d2, fwd_scale, A->k, my_rows, &dF, &j, fin ? &fx : nullptr);
@@ -665,8 +713,9 @@ __device__ __forceinline__ void fast_step_body(const StepArgs *__restrict__ Ap, 
         uint32_t rv = orig;
         Pt4 srec = {0.0, 0.0, 0.0, 0ull};
         if (rev_active)
-            rev_done = fast_ring1<1, true, true>(GS, GS.pts, qx, qy, qz, sx, sy, sz, PCR_INF, dF, rbs, rem_, rev_delta, 1, dF,
-                                                 orig, dRv, rv, my_rows, &D->M, nullptr, pr, &srec);
+            rev_done = fast_ring1<1, true, true, 1, PCR_FAST_U, FAST_RS>(GS, GS.pts, qx, qy, qz, sx, sy, sz, PCR_INF, dF, rbs, rem_,
+                                                                         rev_delta, 1, dF, orig, dRv, rv, my_rows, &D->M, nullptr, pr,
+                                                                         &srec);
         const bool s_known = rev_active & rev_done;
         if (__any(!rev_done)) {
             if (!rev_done) rv = fallback_reverse(Ap, qx, qy, qz, sx, sy, sz, rbs, rem_, dF, orig, my_rows);
@@ -685,6 +734,7 @@ __device__ __forceinline__ void fast_step_body(const StepArgs *__restrict__ Ap, 
     ck[2] = (uint32_t)__builtin_readcyclecounter();
 #endif
     const PCR_CONST_AS StepArgs *A = reload_from(Ap);
+    uint32_t *tickets = A->tickets;
     double acc[17];
 #pragma unroll
     for (int i = 0; i < 17; ++i) acc[i] = 0.0;
@@ -694,30 +744,45 @@ __device__ __forceinline__ void fast_step_body(const StepArgs *__restrict__ Ap, 
         if (A->out_rev) A->out_rev[slot] = r;
         if (A->out_keep) A->out_keep[slot] = keep ? 1 : 0;
     }
-    block_reduce17(acc, (double *)smem, A->block_partials, lb, nb);
+    {
+        double s, s16;
+        wave_reduce17(acc, (double *)smem, s, s16);
+        store17(s, s16, A->tile_partials, ntiles, tile);
+    }
     FAST_STAMP(3);
 #ifdef PCR_BLOCK_TIMES
     ck[3] = (uint32_t)__builtin_readcyclecounter();
-    if (threadIdx.x == 0 && lb < 65536u) {
+    if (lane == 0 && lb < 65536u) {
         uint32_t *o = g_fast_clocks + 16 * (size_t)lb;
         for (int i = 0; i < 4; ++i) { o[i] = ck[i]; o[4 + i] = ckf.t[i]; o[8 + i] = ckr.t[i]; }
     }
 #endif
-    fold_in_kernel(A, lb, nb);
+    if (!tickets) return;  // (fold_partials_kernel follows)
+    wait_stores_acked();
+    ticket_redeem(A, ticket_draw(tickets, tile >> 6, 1u), tile >> 6, 1u, ntiles, (double *)smem);
 }
 
+// The filtered step kernel: one tile per block, a block is ONE wave -- no barrier anywhere, a wave retires (and the
+// hardware hands its slot to the next block) when IT is done.  Measured, 1 M x 1 M, K = 4: 136.2 us against 140.6 / 141.7
+// with two / four such waves per block (which would keep neighbouring tiles on one CU's L1), and 135.7 for round 2's
+// four waves per block with a block-wide reduction and one ticket per block.
 template <int KC>
-__global__ void __launch_bounds__(256, PCR_FAST_WAVES) icp_step_fast_kernel(const StepArgs *__restrict__ Ap) {
-    fast_step_body<KC>(Ap, xcd_remap(blockIdx.x, gridDim.x), gridDim.x);
+__global__ void __launch_bounds__(64, PCR_FAST_WAVES) icp_step_fast_kernel(const StepArgs *__restrict__ Ap) {
+    __shared__ __align__(16) unsigned char smem[WAVE_LDS_BYTES];
+    const PCR_CONST_AS StepArgs *A = reload_from(Ap);
+    if (reload_from(A->dyn)->done) return;  // uniform over the grid
+    fast_tile<KC>(Ap, xcd_remap(blockIdx.x, gridDim.x), gridDim.x, smem);
 }
 
 // Many small problems, ONE launch (BASELINE config C4: a scan set registered pair by pair -- independent fits).
-// Problem p owns the logical blocks [first[p], first[p+1]); each has its own arguments, state, tickets and partials,
-// folds and solves for itself in its own last block, and drops out of later launches once its criteria have fired.
+// Problem p owns the logical blocks (= tiles) [first[p], first[p+1]); each has its own arguments, state, tickets and
+// partials, folds and solves for itself in the wave that hands in its last tile, and drops out of later launches once
+// its criteria have fired.
 template <int KC>
-__global__ void __launch_bounds__(256, PCR_FAST_WAVES) icp_step_batch_kernel(const StepArgs *const *__restrict__ argv,
-                                                                             const uint32_t *__restrict__ first,
-                                                                             uint32_t count) {
+__global__ void __launch_bounds__(64, PCR_FAST_WAVES) icp_step_batch_kernel(const StepArgs *const *__restrict__ argv,
+                                                                            const uint32_t *__restrict__ first,
+                                                                            uint32_t count) {
+    __shared__ __align__(16) unsigned char smem[WAVE_LDS_BYTES];
     const uint32_t b = xcd_remap(blockIdx.x, gridDim.x);
     uint32_t lo = 0, hi = count;  // last p with first[p] <= b
     while (hi - lo > 1u) {
@@ -727,7 +792,9 @@ __global__ void __launch_bounds__(256, PCR_FAST_WAVES) icp_step_batch_kernel(con
         else
             hi = mid;
     }
-    fast_step_body<KC>(argv[lo], b - first[lo], first[lo + 1] - first[lo]);
+    const StepArgs *Ap = argv[lo];
+    if (reload_from(reload_from(Ap)->dyn)->done) return;  // uniform over the problem's blocks
+    fast_tile<KC>(Ap, b - first[lo], first[lo + 1] - first[lo], smem);
 }
 
 // Small clouds: both searches as tiled brute force (LDS-staged tiles, broadcast reads).
@@ -810,12 +877,11 @@ __global__ void __launch_bounds__(256) icp_step_brute_kernel(StepArgs A) {
         if (A.out_rev) A.out_rev[slot] = r;
         if (A.out_keep) A.out_keep[slot] = keep ? 1 : 0;
     }
-    block_reduce17(acc, (double *)smem, A.block_partials, blockIdx.x, gridDim.x);
-    fold_in_kernel(&A, blockIdx.x, gridDim.x);
+    finish_block256(acc, smem, &A, blockIdx.x, (A.m + 63u) >> 6);
 }
 
-// Fold the block partials in a fixed order: block j of the grid owns column j (one of the 17 sums); its 256
-// threads stride over the blocks' values (coalesced), then a tree.  Same order every run => the sums are
+// Fold tile partials in a fixed order (explicit pair lists only: pcr_reduce_pairs): block j of the grid owns column j
+// (one of the 17 sums); its 256 threads stride over the tiles' values (coalesced), then a tree.  Same order every run => the sums are
 // bitwise reproducible run to run.
 __global__ void __launch_bounds__(256) fold_partials_kernel(const double *__restrict__ cols, uint32_t nblocks,
                                                             double *__restrict__ out /*[17]*/) {
@@ -835,7 +901,7 @@ __global__ void __launch_bounds__(256) fold_partials_kernel(const double *__rest
 // Pair lists that already exist (a host-side rejection stage produced them): the same 17 sums over P explicit
 // pairs, same block reduction and fold.  pairs are AoS double[3P].
 __global__ void __launch_bounds__(256) reduce_pairs_kernel(const double *__restrict__ pp, const double *__restrict__ pq,
-                                                           uint32_t P, StepDyn D, double *block_partials) {
+                                                           uint32_t P, StepDyn D, double *tile_partials) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     double acc[17];
 #pragma unroll
@@ -846,7 +912,7 @@ __global__ void __launch_bounds__(256) reduce_pairs_kernel(const double *__restr
         accumulate(acc, true, px, py, pz, qx, qy, qz, sqdist3(px, py, pz, qx, qy, qz), D);
     }
     __shared__ __align__(16) unsigned char smem[REDUCE17_LDS_BYTES];
-    block_reduce17(acc, (double *)smem, block_partials, blockIdx.x, gridDim.x);
+    store_block_tiles256(acc, smem, tile_partials, blockIdx.x, (P + 63u) >> 6);  // (fold_partials_kernel follows)
 }
 
 static double clouds_scale(const pcr_cloud *a, const pcr_cloud *b) {
@@ -1005,11 +1071,11 @@ struct pcr_fit {
     pcr_ctx *ctx;
     const pcr_index *src, *tgt;
     StepArgs args;
-    uint32_t nb, kc, traj_cap;
+    uint32_t nb, kc, traj_cap;  // nb: TILES (64 samples each)
     FitDev *dev_d;        // device state
     FitDev *dev_h;        // pinned host mirror (pcr_fit_read)
     double *partials_d;   // [17]
-    double *block_partials_d;
+    double *block_partials_d;  // StepArgs::tile_partials [17][nb]
     double *traj_d;       // [traj_cap][14]
     uint32_t *samples_d;  // owned copy of a host sample list (pcr_fit_set_samples)
     StepArgs *args_d;     // [2] device copies of args (what the filtered kernel reads): [1] also solves in the kernel
@@ -1056,8 +1122,11 @@ static void fit_upload_args(pcr_fit *f) {
 static thread_local const char *g_last_step_kernel = "none";
 
 // Returns true when the launch also folded (and, if args_d says so, solved) in the step kernel itself.
-static bool launch_step_kernels(pcr_ctx *ctx, const pcr_index *src, const StepArgs &A, uint32_t nb, uint32_t k,
+// nt: tiles (64 samples each).  The filtered kernel runs one single-wave block per tile, every other step kernel
+// ceil(nt / 4) blocks of four waves.
+static bool launch_step_kernels(pcr_ctx *ctx, const pcr_index *src, const StepArgs &A, uint32_t nt, uint32_t k,
                                 double *partials_d, const StepArgs *args_d) {
+    const uint32_t nb = (nt + 3u) / 4u;
     // single-level grids with fp32 shadows and K <= 4: the filtered kernel (tune 5: 1 = never, for A/B runs and tests)
     const bool fast = src->kind == PCR_INDEX_GRID && g_tune[5] != 1 && k <= 4 && A.src.levels == 1 && A.tgt.levels == 1 &&
                       A.src.v[0].shadow && A.tgt.v[0].shadow && args_d;
@@ -1066,13 +1135,13 @@ static bool launch_step_kernels(pcr_ctx *ctx, const pcr_index *src, const StepAr
         {
             ProfScope ps(ctx, PCR_PROF_STEP);
             if (k == 1)
-                hipLaunchKernelGGL(icp_step_fast_kernel<1>, dim3(nb), dim3(256), 0, ctx->stream, args_d);
+                hipLaunchKernelGGL(icp_step_fast_kernel<1>, dim3(nt), dim3(64), 0, ctx->stream, args_d);
             else
-                hipLaunchKernelGGL(icp_step_fast_kernel<4>, dim3(nb), dim3(256), 0, ctx->stream, args_d);
+                hipLaunchKernelGGL(icp_step_fast_kernel<4>, dim3(nt), dim3(64), 0, ctx->stream, args_d);
         }
-        if (A.tickets) return true;  // folded (and, with fit_inline in *args_d, solved) by the step kernel's last block
+        if (A.tickets) return true;  // folded (and, with fit_inline in *args_d, solved) by the step kernel's last wave
         ProfScope ps(ctx, PCR_PROF_FOLD);
-        hipLaunchKernelGGL(fold_partials_kernel, dim3(17), dim3(256), 0, ctx->stream, (const double *)A.block_partials, nb,
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(17), dim3(256), 0, ctx->stream, (const double *)A.tile_partials, nt,
                            partials_d);
         return false;
     }
@@ -1104,7 +1173,7 @@ static bool launch_step_kernels(pcr_ctx *ctx, const pcr_index *src, const StepAr
 #undef LAUNCH_STEP
     if (!A.tickets) {
         ProfScope ps(ctx, PCR_PROF_FOLD);
-        hipLaunchKernelGGL(fold_partials_kernel, dim3(17), dim3(256), 0, ctx->stream, (const double *)A.block_partials, nb,
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(17), dim3(256), 0, ctx->stream, (const double *)A.tile_partials, nt,
                            partials_d);
     }
     return false;
@@ -1194,12 +1263,12 @@ static int step_enqueue(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt
     A.out_fwd = out_fwd_d;
     A.out_rev = out_rev_d;
     A.out_keep = out_keep_d;
-    const uint32_t nb = m ? (m + 255) / 256 : 0;
+    const uint32_t nb = (m + 63u) / 64u;  // tiles
     if (nb == 0) {
         PCR_HIP(hipMemsetAsync(partials_d, 0, sizeof(double) * 17, ctx->stream));
         return PCR_OK;
     }
-    A.block_partials = block_partials_d;
+    A.tile_partials = block_partials_d;
     A.dyn = &sc_d->dyn;
     A.group_partials = group_partials_d;
     A.tickets = tickets_d;  // zero here, and every launch leaves them so
@@ -1217,9 +1286,9 @@ static int step_enqueue(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt
 #define LAUNCH_NORMAL(KC)                                                                                  \
     do {                                                                                                   \
         if (multi)                                                                                         \
-            hipLaunchKernelGGL((icp_step_normal_kernel<KC, true>), dim3(nb), dim3(256), 0, ctx->stream, A);  \
+            hipLaunchKernelGGL((icp_step_normal_kernel<KC, true>), dim3((nb + 3u) / 4u), dim3(256), 0, ctx->stream, A);  \
         else                                                                                               \
-            hipLaunchKernelGGL((icp_step_normal_kernel<KC, false>), dim3(nb), dim3(256), 0, ctx->stream, A); \
+            hipLaunchKernelGGL((icp_step_normal_kernel<KC, false>), dim3((nb + 3u) / 4u), dim3(256), 0, ctx->stream, A); \
     } while (0)
         ProfScope ps(ctx, PCR_PROF_STEP);
         if (k <= 4)
@@ -1244,7 +1313,7 @@ static int step_d_impl(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt,
                        uint32_t *out_rev_d, uint8_t *out_keep_d, const NormalFit *nf) {
     PCR_REQUIRE(ctx && src && tgt && R && T && partials_d, "pcr_icp_step_d: NULL argument");
     PCR_HIP(hipSetDevice(ctx->device));
-    const uint32_t nb = m ? (m + 255) / 256 : 0;
+    const uint32_t nb = (m + 63u) / 64u;  // tiles
     if ((size_t)nb * 17 > ctx->block_partials_cap) {
         if (ctx->block_partials_d) {
             PCR_HIP(hipStreamSynchronize(ctx->stream));
@@ -1282,9 +1351,9 @@ int pcr_icp_step_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
 // the process ends.
 struct NoAllocScratch {
     StepScratch step;
-    double group_partials[17 * (size_t)(PCR_NOALLOC_MAX_SAMPLES / 256u / 64u)];
-    uint32_t tickets[2 + PCR_NOALLOC_MAX_SAMPLES / 256u / 64u];  // zero-initialised; every launch leaves them zero
-    double block_partials[17 * (size_t)(PCR_NOALLOC_MAX_SAMPLES / 256u)];
+    double group_partials[17 * (size_t)(PCR_NOALLOC_MAX_SAMPLES / 64u / 64u)];
+    uint32_t tickets[2 + PCR_NOALLOC_MAX_SAMPLES / 64u / 64u];  // cleared at the start of every call
+    double block_partials[17 * (size_t)(PCR_NOALLOC_MAX_SAMPLES / 64u)];  // [17][tiles]
 };
 static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocScratch)];
 constexpr int NOALLOC_MAX_DEVICES = 64;
@@ -1417,7 +1486,7 @@ int pcr_reduce_pairs(pcr_ctx *ctx, const double *pair_p, const double *pair_q, u
         memset(partials, 0, sizeof(double) * 17);
         return PCR_OK;
     }
-    const uint32_t nb = (P + 255) / 256;
+    const uint32_t nb = (P + 63u) / 64u;  // tiles
     double *buf = nullptr;  // [3P | 3P | 17*nb | 17]
     const size_t n3 = (size_t)P * 3;
     if (hipMalloc(&buf, sizeof(double) * (2 * n3 + 17 * (size_t)nb + 17)) != hipSuccess) {
@@ -1433,7 +1502,7 @@ int pcr_reduce_pairs(pcr_ctx *ctx, const double *pair_p, const double *pair_q, u
     hipError_t e = hipMemcpyAsync(buf, pair_p, sizeof(double) * n3, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(buf + n3, pair_q, sizeof(double) * n3, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(reduce_pairs_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const double *)buf,
+        hipLaunchKernelGGL(reduce_pairs_kernel, dim3((nb + 3u) / 4u), dim3(256), 0, ctx->stream, (const double *)buf,
                            (const double *)(buf + n3), P, D, block_partials);
         hipLaunchKernelGGL(fold_partials_kernel, dim3(17), dim3(256), 0, ctx->stream, (const double *)block_partials, nb,
                            res_d);
@@ -1483,7 +1552,7 @@ int pcr_fit_create(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
         delete f;
         return rc;
     }
-    f->nb = m ? (m + 255) / 256 : 0;
+    f->nb = (m + 63u) / 64u;  // tiles
     f->kc = k;
     f->traj_cap = traj_cap;
     FitDev &I = f->init;
@@ -1518,7 +1587,7 @@ int pcr_fit_create(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt, con
         return e == hipErrorOutOfMemory ? PCR_E_NOMEM : PCR_E_HIP;
     }
     f->args.dyn = &f->dev_d->dyn;
-    f->args.block_partials = f->block_partials_d;
+    f->args.tile_partials = f->block_partials_d;
     f->args.dk_io = f->dk_d;
     f->args.partials_out = f->partials_d;
     fit_upload_args(f);
@@ -1541,7 +1610,7 @@ int pcr_fit_set_samples(pcr_fit *f, const uint32_t *sample_idx, uint32_t m) {
     fit_drop_graph(f);                              // (a captured launch holds the old grid size)
     // allocate everything the new sample set needs FIRST; the fit changes only once all of it exists (a failure leaves
     // it exactly as it was, its device-side arguments still pointing at live memory)
-    const uint32_t nb = m ? (m + 255) / 256 : 0;
+    const uint32_t nb = (m + 63u) / 64u;  // tiles
     const size_t ng = (nb + 63u) / 64u;
     uint32_t *samples_new = nullptr, *tickets_new = nullptr;
     double *bp_new = nullptr, *gp_new = nullptr;
@@ -1566,7 +1635,7 @@ int pcr_fit_set_samples(pcr_fit *f, const uint32_t *sample_idx, uint32_t m) {
     if (bp_new) {
         hipFree(f->block_partials_d);
         f->block_partials_d = bp_new;
-        f->args.block_partials = bp_new;
+        f->args.tile_partials = bp_new;
     }
     if (f->samples_d) hipFree(f->samples_d);
     if (f->dk_d) hipFree(f->dk_d);
@@ -1703,10 +1772,10 @@ int pcr_fit_batch_enqueue_iteration(pcr_fit_batch *b) {
     g_last_step_kernel = b->kc == 1 ? "icp_step_batch_kernel<1>" : "icp_step_batch_kernel<4>";
     ProfScope ps(b->ctx, PCR_PROF_STEP);
     if (b->kc == 1)
-        hipLaunchKernelGGL(icp_step_batch_kernel<1>, dim3(b->blocks), dim3(256), 0, b->ctx->stream, b->argv_d,
+        hipLaunchKernelGGL(icp_step_batch_kernel<1>, dim3(b->blocks), dim3(64), 0, b->ctx->stream, b->argv_d,
                            (const uint32_t *)b->first_d, b->count);
     else
-        hipLaunchKernelGGL(icp_step_batch_kernel<4>, dim3(b->blocks), dim3(256), 0, b->ctx->stream, b->argv_d,
+        hipLaunchKernelGGL(icp_step_batch_kernel<4>, dim3(b->blocks), dim3(64), 0, b->ctx->stream, b->argv_d,
                            (const uint32_t *)b->first_d, b->count);
     PCR_HIP(hipGetLastError());
     return PCR_OK;

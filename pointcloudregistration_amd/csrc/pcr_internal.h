@@ -104,6 +104,7 @@ struct pcr_ctx {
     pcr_prof *prof;
     hipStream_t stream;
     bool own_stream;
+    int cu_count;  // compute units of the device (launch shapes)
     // reusable device scratch for block partials of the fused step (grown on demand, never per call
     // once warm) and a pinned host staging area for the 17 results.
     double *block_partials_d;

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _bench(extra_env, launcher, extra_args, knn=False):
     env = dict(os.environ, **extra_env)
     cmd = [sys.executable] + launcher + [os.path.join(ROOT, "bench.py"), "--points", "200000", "--steps", "6", "--warmup", "1",
-                                         "--no-cpu-baseline"] + ([] if knn else ["--no-knn"]) + extra_args
+                                         "--no-cpu-baseline", "--no-extra"] + ([] if knn else ["--no-knn"]) + extra_args
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]

@@ -1,7 +1,7 @@
 """The in-kernel fold's hand-over, checked in the SHIPPED code object (no GPU needed).
 
 Blocks of a step kernel hand their 17 partial sums to the block that draws a group's last ticket
-(pcr_icp.hip: block_reduce17 / fold17 / fold_in_kernel).  The sums travel as device-scope write-through stores
+(pcr_icp.hip: wave_reduce17 / store17 / ticket_draw / ticket_redeem).  The sums travel as device-scope write-through stores
 (`global_store_dwordx2 ... sc1`), the ticket is a device-scope `global_atomic_add`.  A workgroup barrier does not wait
 for outstanding stores on gfx950, so every storing lane must execute `s_waitcnt vmcnt(0)` after its last such store and
 before the barrier that precedes the ticket -- otherwise the last block of a group can fold a slot that still holds the
@@ -59,29 +59,32 @@ def _kernels(tmp_path):
     return funcs
 
 
-def _check_ticket_order(name, insts):
+def _check_ticket_order(name, insts, need_barrier=True):
     """In program order: after a device-scope partial-sum store (`global_store_dwordx2 ... sc1`) no ticket
-    (`global_atomic_add`) may be reached before an `s_waitcnt` that brings vmcnt to 0 AND a following `s_barrier`."""
-    pending_store = None  # index of the last sc1 store not yet followed by vmcnt(0)
-    acked_then_barrier = True
-    waited = True
+    (`global_atomic_add`) may be reached before an `s_waitcnt` that brings vmcnt to 0.  Where the stores and the ticket
+    come from DIFFERENT waves of a block -- need_barrier: the first ticket of a 256-lane kernel, which hands in the
+    tiles of the block's four waves -- an `s_barrier` must follow that wait as well.  Every other ticket is drawn by
+    the wave that stored (the filtered kernel's blocks are single waves; a group's fold is one wave's work), and
+    `s_waitcnt` is wave-wide."""
+    pending_store = None  # index of the last sc1 store
+    waited = barrier_after_wait = True
     tickets = 0
     for i, ins in enumerate(insts):
         op = ins.split()[0] if ins else ""
         if op.startswith("global_store_dwordx2") and " sc1" in ins + " ":
             pending_store = i
-            waited = False
-            acked_then_barrier = False
+            waited = barrier_after_wait = False
         elif op == "s_waitcnt" and re.search(r"vmcnt\(0\)", ins):
             waited = True
         elif op == "s_barrier":
-            if waited:
-                acked_then_barrier = True
+            barrier_after_wait = waited
         elif op.startswith("global_atomic_add") and not op.startswith("global_atomic_add_f"):
             tickets += 1
-            assert acked_then_barrier, (
-                f"{name}: ticket atomic at instruction {i} ({ins}) follows the sc1 store at {pending_store} "
-                f"({insts[pending_store]}) without `s_waitcnt vmcnt(0)` + `s_barrier` in between")
+            where = (f"{name}: ticket atomic at instruction {i} ({ins}) follows the sc1 store at {pending_store} "
+                     f"({insts[pending_store] if pending_store is not None else '-'}) without ")
+            assert waited, where + "`s_waitcnt vmcnt(0)` in between"
+            if need_barrier and tickets == 1:
+                assert barrier_after_wait, where + "`s_waitcnt vmcnt(0)` + `s_barrier` in between"
     return tickets
 
 
@@ -95,7 +98,10 @@ def test_every_ticket_is_drawn_after_the_partial_sums_were_acknowledged(tmp_path
     for name, insts in sorted(step.items()):
         n_store = sum(1 for x in insts if x.startswith("global_store_dwordx2") and " sc1" in x + " ")
         assert n_store >= 2, f"{name}: no device-scope partial-sum stores found -- has the hand-over changed?"
-        tickets = _check_ticket_order(name, insts)
+        single_wave_blocks = "icp_step_fast_kernel" in name or "icp_step_batch_kernel" in name
+        if single_wave_blocks:
+            assert not any(x.split()[0] == "s_barrier" for x in insts if x), f"{name}: expected single-wave blocks (no s_barrier)"
+        tickets = _check_ticket_order(name, insts, need_barrier=not single_wave_blocks)
         assert tickets >= 2, f"{name}: expected the group ticket and the final ticket, found {tickets} atomics"
         with_tickets += 1
     # the two filtered instances (the headline path), the batch kernel, the fp64 walk, brute force, the normal-aware one
