@@ -41,8 +41,23 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
     return max(min(a, b), min(max(a, b), c));  // selected as one v_med3_u32
 }
 
-// A cell's edge in root units: key_sc = KEY_CELL / h in every grid (pcr_core.hip), 2.5 h^2 <-> 2^32 keys.
-#define KEY_CELL 41448.97f
+// A cell's edge in key-space units: key_sc = KEY_CELL / h in every grid (pcr_core.hip).  An integer, and 1.5 cells stay
+// below 2^15: y and z differences of everything the 3x3x3 walk can settle fit a signed 16-bit lane.  Keys of interest
+// (squared distances up to 2.5 h^2, above everything that walk can settle) lie below KEY_RANGE = 1.19e9; the largest key
+// a row can produce, (2 h)^2 + 2 * 32768^2 = 4.06e9, still fits 32 bits and stays below the sentinel.
+#define KEY_CELL 21844.0f
+constexpr double KEY_RANGE = 2.5 * 21844.0 * 21844.0;
+constexpr double KEY_MAX_ROOT = 1.5811388300841898 * 21844.0;  // sqrt(KEY_RANGE)
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+// key-space integer coordinate of a cloud coordinate (the expression shadow_kernel uses: pcr_core.hip)
+__device__ __forceinline__ int key_coord(double v, double lo, double sc) { return __double2int_rn((v - lo) * sc); }
+// the squared distance, in key units, between the query (QX; Qyz = Y16 | Z16 << 16) and a shadow record: 4 instructions
+__device__ __forceinline__ uint32_t shadow_key_d2(uint32_t QX, uint32_t Qyz, uint32_t rec_x, uint32_t rec_yz) {
+    const int dx = (int)(QX - rec_x);
+    const s16x2 dyz = __builtin_bit_cast(s16x2, Qyz) - __builtin_bit_cast(s16x2, rec_yz);  // v_pk_sub_i16, wrapping
+    const int dyz2 = __builtin_amdgcn_sdot2(dyz, dyz, 0, false);                          // v_dot2_i32_i16
+    return (uint32_t)__mul24(dx, dx) + (uint32_t)dyz2;                                     // v_mad_i32_i24
+}
 // One axis: the cell the key-space coordinate Q falls in (clamped to the grid), and the distances from Q to that cell's
 // low and high face, each shrunk by eps and clamped at 0.
 __device__ __forceinline__ void cell_and_gaps(float Q, int g, float eps, int &c, float &gl, float &gh) {
@@ -162,7 +177,7 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
                                            StageClock *clk = nullptr, Pt4 *win = nullptr, uint32_t *win_pos = nullptr) {
     constexpr int KP = KC + 2;
     const uint32_t *__restrict__ cs = g.cs;
-    const float4 *__restrict__ shadow = g.shadow;
+    const uint2 *__restrict__ shadow = g.shadow;
     const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
     const double S = g.key_S;
     // ---- the query in key space, and the geometry of its cell there, in fp32.  One unit ("root unit") is the square
@@ -207,11 +222,15 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
     // The four boundaries cs[c-1..c+2] of a row's three cells come with ONE 16-byte buffer load (the table is padded by
     // an entry either side, pcr_core.hip; a row outside the grid may read anything or nothing -- it is masked).
     // A row's entry: x = position of the first point of its cell cx-1, y = the populations of cells cx-1, cx, cx+1 (one
-    // byte each) and, in the top byte, the row's slab distance in key units >> 24, rounded down.  Non-empty rows are
+    // byte each) and, in the top byte, the row's slab distance in key units >> 22, rounded down (saturating: a smaller
+    // slab distance only prunes less).  Non-empty rows are
     // appended to the lane's column of the LDS table in order of slab-distance class (centre, 4 faces, 4 edges).
     const uint32_t cells = (uint32_t)gx * (uint32_t)gy * (uint32_t)gz;
     const __amdgpu_buffer_rsrc_t rs_cs = __builtin_amdgcn_make_buffer_rsrc((void *)(cs - 1), 0, (int)((cells + 3u) * 4u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_sh = __builtin_amdgcn_make_buffer_rsrc((void *)shadow, 0, (int)(g.n * 16u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_sh = __builtin_amdgcn_make_buffer_rsrc((void *)shadow, 0, (int)(g.n * 8u), 0x00020000);
+    // the query in integer key space (what the candidates' shadows are subtracted from)
+    const uint32_t QX = (uint32_t)key_coord(sx, g.lo[0], g.key_sc);
+    const uint32_t Qyz = ((uint32_t)key_coord(sy, g.lo[1], g.key_sc) & 0xFFFFu) | ((uint32_t)key_coord(sz, g.lo[2], g.key_sc) << 16);
     STAGE_CLOCK(clk, 0);
     uint32_t cnt = 0;
     {
@@ -238,7 +257,7 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
             const uint32_t tot = p3 - p0;
             ok &= !(open & (tot > 255u));  // the payload holds 8 bits of offset: a longer row is the fp64 walk's business
             if (open & (tot != 0u)) {
-                rowtab[cnt * RS] = make_uint2(p0, (p1 - p0) | ((p2 - p1) << 8) | ((p3 - p2) << 16) | (rowk & 0xFF000000u));
+                rowtab[cnt * RS] = make_uint2(p0, (p1 - p0) | ((p2 - p1) << 8) | ((p3 - p2) << 16) | (min(rowk >> 22, 255u) << 24));
                 ++cnt;
             }
         }
@@ -267,7 +286,7 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
         for (int tries = 0; tries < TRIES; ++tries) {
             if (want) {
                 const uint2 row = rowtab[ri * RS];
-                const uint32_t n0 = row.y & 255u, n1 = (row.y >> 8) & 255u, n2 = (row.y >> 16) & 255u, rk = row.y & 0xFF000000u;
+                const uint32_t n0 = row.y & 255u, n1 = (row.y >> 8) & 255u, n2 = (row.y >> 16) & 255u, rk = (row.y >> 24) << 22;
                 const uint32_t UB = sat_add(min(T.t[KC - 1], bound_k) | ~KEY_DIST_MASK, delta);
                 const bool trim_lo = sat_add(rk, gxl_k) > UB, trim_hi = sat_add(rk, gxh_k) > UB;
                 p2 = row.x + (trim_lo ? n0 : 0u);
@@ -280,12 +299,16 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
         }
         const uint32_t rem2 = e2 - p2, tot = rem + rem2;
         const uint32_t base2 = p2 - rem, d1 = p - pb, d2 = base2 - pb2;
-        u32x4 c[U];
+        uint32_t cx[U], cyz[U];  // (scalars on purpose: this compiler turns a 2-vector filled element by element from the
+                                 // builtin's result into TWO COPIES OF THE FIRST DWORD, and loads only that one)
         uint32_t pay[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const bool in1 = (uint32_t)u < rem;
-            c[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_sh, ((in1 ? p : base2) << 4) + 16u * (uint32_t)u, 0, 0);
+            const auto rec = __builtin_amdgcn_raw_buffer_load_b64(rs_sh, ((in1 ? p : base2) << 3) + 8u * (uint32_t)u, 0, 0);
+            static_assert(sizeof(rec) == 8, "a shadow record is two dwords");
+            cx[u] = rec[0];
+            cyz[u] = rec[1];
             pay[u] = (in1 ? d1 : d2) + (uint32_t)u;
         }
         if (rem >= (uint32_t)U) {
@@ -297,11 +320,7 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float dx = Qx - __uint_as_float(c[u].x), dy = Qy - __uint_as_float(c[u].y), dz = Qz - __uint_as_float(c[u].z);
-            float D = dx * dx;
-            D = fmaf(dy, dy, D);
-            D = fmaf(dz, dz, D);
-            uint32_t key = (cvt_u32_sat(D) & KEY_DIST_MASK) | pay[u];
+            uint32_t key = (shadow_key_d2(QX, Qyz, cx[u], cyz[u]) & KEY_DIST_MASK) | pay[u];
             asm volatile("" : "+v"(key));  // computed in every lane, selected below: no branch per slot
             T.insert((uint32_t)u < tot ? key : KEY_SENTINEL);
         }
@@ -358,6 +377,12 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
             const bool in = (T.t[j] != KEY_SENTINEL) & (dd < max_d2);
             ed[NS + j] = in ? dd : max_d2;
             ei[NS + j] = in ? (uint32_t)crec[j].w : PCR_NO_INDEX;
+            // A listed candidate farther than 1.5 h along y or z has WRAPPED to a key far below its distance.  These KC
+            // keys are what every pruning bound of the walk came from (UB: T.t[KC - 1]): with all of them honest --
+            // key >= exact - delta, checked here against the exact distance -- the walk's proof stands as it is; one that
+            // is not sends the lane to the fp64 walk.  (Unlisted candidates need no check: a key that is too small only
+            // makes the verification below harder to pass.)
+            ok &= !((T.t[j] != KEY_SENTINEL) & (key_floor(dd, S) > sat_add(T.t[j] | ~KEY_DIST_MASK, delta)));
         }
     }
     ei[KC + NS] = PCR_NO_INDEX;
@@ -503,9 +528,9 @@ __device__ __forceinline__ void multi_lane_search(const MultiView &M, const Mult
                         // with a lower index must still be seen)
                         const double reach = fmin(max_d2, top.worst_d() * (1.0 + 4.440892098500626e-16) + 4.9406564584124654e-324);
                         const uint32_t delta =
-                            g.key_delta + (uint32_t)fmin((1.0 - bound_scale) * 1.1 * 4294967296.0 +
-                                                             2.0 * 65536.0 * 1.01 * extra_margin * g.key_sc + 2.0,
-                                                         1073741824.0);
+                            g.key_delta + (uint32_t)fmin((1.0 - bound_scale) * 1.1 * KEY_RANGE +
+                                                             2.0 * KEY_MAX_ROOT * 1.01 * extra_margin * g.key_sc + 2.0,
+                                                         268435456.0);
                         double dk;
                         uint32_t ik;
                         fast_ring1<KC, XF, false>(g, lvl_pts, qx, qy, qz, sx, sy, sz, reach, PCR_INF, bound_scale, extra_margin,

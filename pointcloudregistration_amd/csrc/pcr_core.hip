@@ -219,14 +219,15 @@ __global__ void __launch_bounds__(256) pos_of_kernel(const Pt4 *__restrict__ pts
     if (i < n) pos_of[(uint32_t)pts[i].w] = i;
 }
 
-// fp32 key-space copy of a level's points (GridView::shadow)
+// integer key-space copy of a level's points (GridView::shadow): the same expression the query side uses (key_coord)
 __global__ void __launch_bounds__(256) shadow_kernel(const Pt4 *__restrict__ pts, uint32_t n, double lo0, double lo1,
-                                                     double lo2, double sc, float4 *__restrict__ out) {
+                                                     double lo2, double sc, uint2 *__restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         const Pt4 p = pts[i];
-        out[i] = make_float4((float)((p.x - lo0) * sc), (float)((p.y - lo1) * sc), (float)((p.z - lo2) * sc),
-                             __uint_as_float((uint32_t)p.w));
+        const uint32_t X = (uint32_t)__double2int_rn((p.x - lo0) * sc), Y = (uint32_t)__double2int_rn((p.y - lo1) * sc),
+                       Z = (uint32_t)__double2int_rn((p.z - lo2) * sc);
+        out[i] = make_uint2(X, (Y & 0xFFFFu) | (Z << 16));
     }
 }
 
@@ -1340,21 +1341,24 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
         }
         hipLaunchKernelGGL(pos_of_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ix->pts_d, n, ix->pos_of_d);
         // ---- key-space shadows for the filtered search, level by level (each level has its own cell size, hence its own
-        // key scale), and only while fp32 still resolves distances far below a cell (key_delta <= 2^24 of 2^32, i.e. grids
-        // up to ~14 000 cells along an axis).  A single-level index with shadows takes the filtered step kernel; the levels
-        // of a nested one take the filtered walk inside multi_lane_search.
+        // key scale).  Integer coordinates: the error bound no longer grows with the grid's extent, so every level of every
+        // index gets them as long as its coordinates fit 31 bits (grids up to ~98 000 cells along an axis).  A
+        // single-level index with shadows takes the filtered step kernel; the levels of a nested one take the filtered
+        // walk inside multi_lane_search.
         for (int l = 0; l < M.levels; ++l) {
             GridView &V = M.v[l];
             const uint64_t B_cells = ix->cells[l];
-            const double sc = (double)41448.97f / V.h;  // KEY_CELL (fast_search.h) root units per cell: 2.5 h^2 <-> 2^32 keys
+            const double sc = 21844.0 / V.h;  // KEY_CELL (fast_search.h) units per cell
             double ext = 0;
             for (int a = 0; a < 3; ++a) ext = fmax(ext, V.hi[a] - V.lo[a]);
-            // per-axis error of a coordinate difference in root units: both operands rounded to fp32 (|Q| <= ext + 4h)
+            // per-axis error of a coordinate difference in units: the point and the query each rounded to an integer
+            const double e_axis = 1.0 * 1.01;
+            // |key - S d2| <= 2 sqrt(D) sqrt(3) e + 3 e^2 + 4096 (truncation of the key's low 12 bits), sqrt(D) <= sqrt(2.5) cells
+            const double delta = 2.0 * 1.5811388300841898 * 21844.0 * 1.7320508075688774 * e_axis + 3.0 * e_axis * e_axis + 4096.0 + 64.0;
+            // what the walk's fp32 geometry (the query's cell, its gaps to the faces) rounds by: |Q| <= (ext + 4h) * sc
             const double eps = 1.1920928955078125e-07 * (ext + 4.0 * V.h) * sc * 1.01;
-            // |key - S d2| <= 2 sqrt(D) sqrt(3) eps + 3 eps^2 + 8*2^-24 D (fp32 arithmetic) + 4096 (truncation), D <= 2^32
-            const double delta = 2.0 * 65536.0 * 1.7320508075688774 * eps * 1.01 + 3.0 * eps * eps + 2048.0 + 4096.0 + 64.0;
-            if (delta <= 16777216.0 && B_cells + 3 < (1ull << 30) && (uint64_t)V.n < (1ull << 28)) {  // 32-bit byte offsets
-                if (!ix->shadow_d) BUILD_HIP(hipMalloc(&ix->shadow_d, sizeof(float4) * (size_t)n));
+            if ((ext + 8.0 * V.h) * sc < 2147483648.0 && B_cells + 3 < (1ull << 30) && (uint64_t)V.n < (1ull << 28)) {  // 32-bit byte offsets
+                if (!ix->shadow_d) BUILD_HIP(hipMalloc(&ix->shadow_d, sizeof(uint2) * (size_t)n));
                 const size_t off_l = (size_t)(V.pts - ix->pts_d);
                 hipLaunchKernelGGL(shadow_kernel, dim3((V.n + 255) / 256), dim3(256), 0, ctx->stream, (const Pt4 *)V.pts, V.n,
                                    V.lo[0], V.lo[1], V.lo[2], sc, ix->shadow_d + off_l);
@@ -1363,7 +1367,7 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
                 V.key_S = sc * sc;
                 V.key_invS = 1.0 / V.key_S;
                 V.key_delta = (uint32_t)ceil(delta);
-                V.key_eps = (float)(4.0 * eps + 1.0);  // 2^-21 of the largest coordinate: a few fp32 roundings
+                V.key_eps = (float)(4.0 * eps + 1.0);  // a few fp32 roundings of the largest coordinate, and a unit
                 for (int a = 0; a < 3; ++a) V.key_ext[a] = (float)((V.hi[a] - V.lo[a]) * sc * 1.000001);
             }
         }
@@ -1378,7 +1382,7 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
         ix->info.mean_occupancy = (double)n / (double)(occupied_total ? occupied_total : 1);
         ix->info.max_occupancy = max_occ;
         ix->info.levels = (uint32_t)M.levels;
-        ix->info.device_bytes = (sizeof(Pt4) + 8 + (ix->shadow_d ? 16 : 0)) * (uint64_t)n + 4 * (cells_total + M.levels) + cells_total / 8;
+        ix->info.device_bytes = (sizeof(Pt4) + 8 + (ix->shadow_d ? 8 : 0)) * (uint64_t)n + 4 * (cells_total + M.levels) + cells_total / 8;
     }
     release(B);
     if (stats_d) hipFree(stats_d);

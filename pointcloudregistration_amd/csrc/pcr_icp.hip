@@ -70,9 +70,9 @@ PCR_HD inline bool make_dyn(const double *R, const double *T, const double *c_sr
     D.rev_bound_scale = (1.0 - 3.0 * defect) * (1.0 - 1.8189894035458565e-12);
     const double scale = fmax(fabs(T[0]) + fabs(T[1]) + fabs(T[2]), 0.0) + cloud_scale;
     D.rev_extra_margin = 3.637978807091713e-12 * scale;  // 2^-38: rounding of the inverse map
-    D.rev_delta = src_key_delta + (uint32_t)fmin((1.0 - D.rev_bound_scale) * 1.1 * 4294967296.0 +
-                                                     2.0 * 65536.0 * 1.01 * D.rev_extra_margin * src_key_sc + 2.0,
-                                                 1073741824.0);
+    D.rev_delta = src_key_delta + (uint32_t)fmin((1.0 - D.rev_bound_scale) * 1.1 * KEY_RANGE +
+                                                     2.0 * KEY_MAX_ROOT * 1.01 * D.rev_extra_margin * src_key_sc + 2.0,
+                                                 268435456.0);
     D.done = 0;
     D.disp_bound = __builtin_huge_valf();
     return ok;

@@ -52,15 +52,17 @@ struct GridView {
     double margin;        // absolute safety margin on face distances, ~2^-40 * coordinate scale
     int g[3];             // grid dimensions
     uint32_t n;
-    // ---- fp32 "key space" copy of the points for the filtered search (fast_search.h); NULL when the index has none
-    // (brute force, nested levels, grids so large that fp32 resolves too little).  shadow[i] = (pts[i] - lo) * key_sc
-    // rounded to fp32 (w: the original index, as bits).  key_sc is chosen so that a squared distance of 2.5 h^2 --
-    // above every distance the 3x3x3 walk can settle -- maps to 2^32: a candidate's squared distance, computed in
-    // fp32 from the shadows and truncated, is a 32-bit integer KEY that orders candidates almost like the exact fp64
-    // distance does; key_delta bounds |key - exact| for every query within 4 cells of the grid's box (both roundings
-    // to fp32, the fp32 arithmetic, the truncation), in key units.  The exact fp64 arithmetic decides every result.
-    const float4 *shadow;
-    double key_sc, key_S, key_invS;  // key = key_S * d2, key_S = key_sc^2
+    // ---- integer "key space" copy of the points for the filtered search (fast_search.h); NULL when the index has none
+    // (brute force, grids beyond 2^30 cells).  One key-space unit is h / 21844 (KEY_CELL): a cell's edge is an INTEGER
+    // number of units and 1.5 cells fit 15 bits.  shadow[i] = {X, Y16 | Z16 << 16} with (X, Y, Z) = (pts[i] - lo) *
+    // key_sc rounded to the nearest integer, X whole, Y and Z modulo 2^16 -- 8 bytes per point.  A candidate's squared
+    // distance in these units, from ONE packed 16-bit subtract (wrapping: exact while |dy|, |dz| < 1.5 h), one 16-bit dot
+    // product and one 24-bit multiply-add, is a 32-bit integer KEY that orders candidates almost like the exact fp64
+    // distance does; key_delta bounds |key - exact| (both roundings to integers, the truncation of the key's low bits)
+    // for candidates less than 1.5 h away along y and z -- a farther one wraps to a key that is TOO SMALL, which the
+    // walk detects when it evaluates the candidate exactly.  The exact fp64 arithmetic decides every result.
+    const uint2 *shadow;
+    double key_sc, key_S, key_invS;  // key = key_S * d2, key_S = key_sc^2, key_sc = KEY_CELL / h
     uint32_t key_delta;
     float key_eps;                   // what every fp32 gap of the walk's geometry is shrunk by, in root units
     float key_ext[3];                // (hi - lo) * key_sc, rounded up
@@ -175,7 +177,7 @@ struct pcr_index {
     int kind;  // PCR_INDEX_GRID or PCR_INDEX_BRUTE
     uint32_t n;
     pcr::Pt4 *pts_d;    // [n] cell order (GRID) / original order (BRUTE)
-    float4 *shadow_d;   // [n] same order: fp32 key-space copy (GridView::shadow), single-level grids only
+    uint2 *shadow_d;    // [n] same order: integer key-space copy (GridView::shadow)
     uint32_t *pos_of_d; // [n] original index -> position in pts_d
     uint32_t *order_d;  // [n] positions in pts_d ordered by grid brick: the processing order of "all samples"
     pcr::MultiView view;
