@@ -297,24 +297,34 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
                 want = (e2 == p2) & (ri < cnt);
             }
         }
-        const uint32_t rem2 = e2 - p2, tot = rem + rem2;
-        const uint32_t base2 = p2 - rem, d1 = p - pb, d2 = base2 - pb2;
-        uint32_t cx[U], cyz[U];  // (scalars on purpose: this compiler turns a 2-vector filled element by element from the
-                                 // builtin's result into TWO COPIES OF THE FIRST DWORD, and loads only that one)
+        // Two records (16 bytes) per load: the current row takes an EVEN number of slots -- when an odd number of its
+        // candidates is left, the slot behind the last one is a dummy (it reads whatever follows the row and is masked) --
+        // so that every pair of slots (2v, 2v+1) reads two neighbouring positions of one row.  Half the memory
+        // instructions, and half the requests the L1 has to look up, per candidate.
+        static_assert(U % 2 == 0, "slots are loaded in pairs");
+        const uint32_t rem2 = e2 - p2;
+        const uint32_t remE = (rem + 1u) & ~1u, totE = remE + rem2;
+        const uint32_t dummy = (rem & 1u) ? rem : 0xFFFFFFFFu;
+        const uint32_t baseB = p2 - remE, d1 = p - pb, d2 = baseB - pb2;
+        uint32_t cx[U], cyz[U];  // (scalars on purpose: this compiler turns a small vector filled element by element from
+                                 // the builtin's result into copies of its FIRST dword, and loads only that one)
         uint32_t pay[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool in1 = (uint32_t)u < rem;
-            const auto rec = __builtin_amdgcn_raw_buffer_load_b64(rs_sh, ((in1 ? p : base2) << 3) + 8u * (uint32_t)u, 0, 0);
-            static_assert(sizeof(rec) == 8, "a shadow record is two dwords");
-            cx[u] = rec[0];
-            cyz[u] = rec[1];
-            pay[u] = (in1 ? d1 : d2) + (uint32_t)u;
+        for (int v = 0; v < U / 2; ++v) {
+            const bool inA = (uint32_t)(2 * v) < rem;
+            const auto rec = __builtin_amdgcn_raw_buffer_load_b128(rs_sh, ((inA ? p : baseB) << 3) + 16u * (uint32_t)v, 0, 0);
+            static_assert(sizeof(rec) == 16, "two shadow records");
+            cx[2 * v] = rec[0];
+            cyz[2 * v] = rec[1];
+            cx[2 * v + 1] = rec[2];
+            cyz[2 * v + 1] = rec[3];
+            pay[2 * v] = (inA ? d1 : d2) + (uint32_t)(2 * v);
+            pay[2 * v + 1] = pay[2 * v] + 1u;
         }
         if (rem >= (uint32_t)U) {
             p += (uint32_t)U;
         } else {
-            p = p2 + min((uint32_t)U - rem, rem2);
+            p = p2 + min((uint32_t)U - remE, rem2);
             e = e2;
             pb = pb2;
         }
@@ -322,7 +332,7 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
         for (int u = 0; u < U; ++u) {
             uint32_t key = (shadow_key_d2(QX, Qyz, cx[u], cyz[u]) & KEY_DIST_MASK) | pay[u];
             asm volatile("" : "+v"(key));  // computed in every lane, selected below: no branch per slot
-            T.insert((uint32_t)u < tot ? key : KEY_SENTINEL);
+            T.insert((((uint32_t)u < totE) & ((uint32_t)u != dummy)) ? key : KEY_SENTINEL);
         }
         alive = (p < e) | (ri < cnt);
     }

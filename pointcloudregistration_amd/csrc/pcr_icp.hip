@@ -599,6 +599,12 @@ __device__ PCR_FALLBACK_INLINE uint32_t fallback_reverse(const StepArgs *__restr
     return rt.idx[0];
 }
 
+#ifndef PCR_FAST_U_FWD
+#define PCR_FAST_U_FWD 8  // shadow records per trip of the forward / reverse search (fast_search.h: PCR_FAST_U)
+#endif
+#ifndef PCR_FAST_U_REV
+#define PCR_FAST_U_REV 6
+#endif
 constexpr int FAST_RS = 64;  // the filtered kernel's blocks are single waves: 64 lanes per row of the LDS row table
 
 // One tile -- 64 samples, one lane each -- of one problem.  smem: the wave's WAVE_LDS_BYTES (row table, then the
@@ -669,7 +675,7 @@ __device__ __forceinline__ void fast_tile(const StepArgs *__restrict__ Ap, uint3
             bound_d2 = (double)(s2 * s2) * 1.000001;  // inf stays inf
         }
         if (fin)  // NeighborSet.back() = K-th nearest (:91-92)
-            fwd_done = fast_ring1<KC, false, false, 1, PCR_FAST_U, FAST_RS>(GT, GT.pts, px, py, pz, px, py, pz, fmax_d2, bound_d2,
+            fwd_done = fast_ring1<KC, false, false, 1, PCR_FAST_U_FWD, FAST_RS>(GT, GT.pts, px, py, pz, px, py, pz, fmax_d2, bound_d2,
                                                                             fwd_scale, 0.0, GT.key_delta, A->k, 0.0, 0u, dF, j,
                                                                             my_rows, (const Rigid *)nullptr, &fx, pf, nullptr, &qpos);
         q_known = fin & fwd_done & (qpos != PCR_NO_INDEX);  // the walk hands over q's position with its index
@@ -713,7 +719,7 @@ __device__ __forceinline__ void fast_tile(const StepArgs *__restrict__ Ap, uint3
         uint32_t rv = orig;
         Pt4 srec = {0.0, 0.0, 0.0, 0ull};
         if (rev_active)
-            rev_done = fast_ring1<1, true, true, 1, PCR_FAST_U, FAST_RS>(GS, GS.pts, qx, qy, qz, sx, sy, sz, PCR_INF, dF, rbs, rem_,
+            rev_done = fast_ring1<1, true, true, 1, PCR_FAST_U_REV, FAST_RS>(GS, GS.pts, qx, qy, qz, sx, sy, sz, PCR_INF, dF, rbs, rem_,
                                                                          rev_delta, 1, dF, orig, dRv, rv, my_rows, &D->M, nullptr, pr,
                                                                          &srec);
         const bool s_known = rev_active & rev_done;

@@ -8,6 +8,9 @@
 #include <vector>
 #include "knn_device.h"
 #include "fast_search.h"
+#ifndef PCR_KNN_U
+#define PCR_KNN_U 6  // shadow records per trip of the free-query search
+#endif
 
 namespace pcr {
 
@@ -84,7 +87,7 @@ __global__ void __launch_bounds__(256, 4) knn_fast_kernel(const MultiView *__res
     uint32_t ik;
     bool done = !active;
     if (active)
-        done = fast_ring1<KC, false, false, 3, 4>(G, G.pts, qx, qy, qz, qx, qy, qz, max_d2, PCR_INF, scale, 0.0, G.key_delta, k, 0.0,
+        done = fast_ring1<KC, false, false, 3, PCR_KNN_U>(G, G.pts, qx, qy, qz, qx, qy, qz, max_d2, PCR_INF, scale, 0.0, G.key_delta, k, 0.0,
                                             0u, dk, ik, my_rows, (const Rigid *)nullptr, &ex);
     uint32_t *oi = out_idx + (size_t)i * k;
     double *od = out_d2 ? out_d2 + (size_t)i * k : nullptr;
