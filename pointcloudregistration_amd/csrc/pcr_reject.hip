@@ -79,6 +79,285 @@ __global__ void __launch_bounds__(256) reject_stat_kernel(MultiView src, MultiVi
     d_out[i] = fabs(s[0] - s[1]);  // (:77)
 }
 
+// ---- single-level grids: ONE WAVE per search ---------------------------------------------------------------------
+// K = MSN = 25 does not fit a lane: a sorted 32-slot list in registers is 96 registers and a 32-step insert per accepted
+// candidate (the kernel above: 292 VGPRs, one wave per SIMD, 16 ms per 620 k pairs).  Here the 64 lanes of a wave search
+// for ONE point together: the K best so far live ACROSS the lanes (lane j holds rank j), the candidates of a shell --
+// its rows' ranges, laid end to end through a prefix sum -- are read 64 at a time, one per lane (neighbouring lanes read
+// neighbouring records), and a candidate that beats the current K-th is inserted with one compare per lane and a shift
+// by one lane.  Same shells, ball chords, pruning and stopping rule as grid_search / coop_shells (knn_device.h), same
+// total order (d2, original index): the same exact K nearest.  What the statistic needs of them -- the coordinates of
+// those below MSD -- is gathered by the lanes that hold them and added nearest first, as the reference adds them.
+// Lane exchanges without address arithmetic: ds_swizzle swaps within 32 lanes by a constant XOR mask, a DPP move shifts
+// the whole wave by one lane (HIP's __shfl_* compute a byte address per call and go through ds_bpermute: 7 instructions
+// per 32-bit word where these take one).
+template <int M>
+__device__ __forceinline__ uint32_t xor_lane(uint32_t v) {
+    if constexpr (M >= 32)
+        return (uint32_t)__shfl_xor((int)v, M, 64);
+    else
+        return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (M << 10) | 0x1f);
+}
+template <int M>
+__device__ __forceinline__ double xor_lane(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = xor_lane<M>((uint32_t)b), hi = xor_lane<M>((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ uint32_t lane_below(uint32_t v) {  // lane l receives lane l-1's value (lane 0: 0)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ double lane_below(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = lane_below((uint32_t)b), hi = lane_below((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// one compare-exchange step of the bitonic network over (d, ci): partner lane ^ JJ, ascending where (lane & KK) == 0
+template <int KK, int JJ>
+__device__ __forceinline__ void bitonic_step(double &d, uint32_t &ci, int lane) {
+    const double od = xor_lane<JJ>(d);
+    const uint32_t oi = xor_lane<JJ>(ci);
+    const bool keep_min = ((lane & KK) == 0) == ((lane & JJ) == 0);
+    const bool other_first = better(od, oi, d, ci);
+    const bool swap = keep_min ? other_first : (!other_first & ((od != d) | (oi != ci)));
+    d = swap ? od : d;
+    ci = swap ? oi : ci;
+}
+template <int KK, int JJ>
+__device__ __forceinline__ void bitonic_stage(double &d, uint32_t &ci, int lane) {
+    bitonic_step<KK, JJ>(d, ci, lane);
+    if constexpr (JJ > 1) bitonic_stage<KK, JJ / 2>(d, ci, lane);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    const int lane = (int)(threadIdx.x & 63u);
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)v, m, 64);
+        v += lane >= m ? o : 0u;
+    }
+    return v;
+}
+// (PCR_REJ_DIAG: a diagnostic build's counters -- searches, shells, row groups, chunks, candidates, insertions; measured
+// on the kept pairs of a converged 1 M x 1 M fit, per search: 2.4 shells, 7.8 row groups, 5.9 chunks, 259 candidates,
+// 48 insertions -- the source side asks for the neighbours of a TRANSFORMED point in the UNtransformed cloud (:52,:75),
+// 4.5 cells off the surface at that fit's translation, so its searches reach 5-6 cells out)
+#ifdef PCR_REJ_DIAG
+__device__ unsigned long long g_rej_diag[8];
+#define RDIAG(i, v) do { if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_rej_diag[i], (unsigned long long)(v)); } while (0)
+#else
+#define RDIAG(i, v) do { } while (0)
+#endif
+// (x, y, z): the point, wave-uniform.  lds: 192 words of the wave's own.  Returns the statistic, wave-uniform.
+__device__ __forceinline__ double wave_sq_dist_to_centroid(const GridView &g, const uint32_t *__restrict__ pos_of, double x,
+                                                           double y, double z, int k, double msd, uint32_t *lds) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const Pt4 *__restrict__ pts = g.pts;
+    const uint32_t *__restrict__ cs = g.cs;
+    RDIAG(0, 1);  // searches
+    double Ld = PCR_INF;           // lane j: the (j+1)-th best so far
+    uint32_t Li = PCR_NO_INDEX;
+    double tau_d = PCR_INF;        // the k-th best so far (lane k-1's), wave-uniform
+    uint32_t tau_i = PCR_NO_INDEX;
+    bool empty = true;             // nothing has been listed yet (wave-uniform)
+    if (isfinite(x) && isfinite(y) && isfinite(z)) {
+        const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
+        const double h = g.h, inv_h = g.inv_h, lox = g.lo[0], loy = g.lo[1], loz = g.lo[2];
+        const int cx = cell_coord(x, lox, inv_h, gx), cy = cell_coord(y, loy, inv_h, gy), cz = cell_coord(z, loz, inv_h, gz);
+        const double margin = g.margin + 9.094947017729282e-13 * (fabs(x) + fabs(y) + fabs(z));
+        const double bound_scale = 1.0 - 1.8189894035458565e-12, inv_bs = 1.0 / bound_scale;
+        double ox = fmax(fmax(lox - x, x - g.hi[0]), 0.0) - margin;
+        double oy = fmax(fmax(loy - y, y - g.hi[1]), 0.0) - margin;
+        double oz = fmax(fmax(loz - z, z - g.hi[2]), 0.0) - margin;
+        ox = ox > 0.0 ? ox : 0.0;
+        oy = oy > 0.0 ? oy : 0.0;
+        oz = oz > 0.0 ? oz : 0.0;
+        const double ox2 = ox * ox, oy2 = oy * oy, oz2 = oz * oz;
+        int px0 = 1, px1 = 0, py0 = 1, py1 = 0, pz0 = 1, pz1 = 0;  // the box scanned so far (empty)
+        const int rmax = max(max(gx, gy), gz);
+        int r = 0;
+        for (;;) {
+            // next radius (grid_search's rule): double, but never past what the ball of everything that can still matter needs
+            if (r == 0) {
+                r = 1;
+            } else {
+                int rn = 2 * r;
+                if (tau_d < PCR_INF) {
+                    const double cells_needed = (sqrt(tau_d * inv_bs) + margin) * inv_h + 2.0;
+                    const int need = cells_needed < (double)rmax ? (int)cells_needed : rmax;
+                    rn = max(r + 1, min(rn, need));
+                }
+                r = min(rn, rmax);
+            }
+            RDIAG(1, 1);  // shells
+            const int x0 = max(cx - r, 0), x1 = min(cx + r, gx - 1);
+            const int y0 = max(cy - r, 0), y1 = min(cy + r, gy - 1);
+            const int z0 = max(cz - r, 0), z1 = min(cz + r, gz - 1);
+            const int ny = y1 - y0 + 1;
+            const uint32_t nent = 2u * (uint32_t)ny * (uint32_t)(z1 - z0 + 1);  // a row has up to two new x-segments
+            for (uint32_t ebase = 0; ebase < nent; ebase += 64u) {
+                // ---- every lane: one (row, segment) of the shell -> its range of positions
+                RDIAG(2, 1);  // entry groups
+                const uint32_t ent = ebase + (uint32_t)lane;
+                uint32_t p = 0, count = 0;
+                if (ent < nent) {
+                    uint32_t row = ent >> 1;
+                    const uint32_t seg = ent & 1u;
+                    // the first cube's rows nearest first (the point's own row, the four beside it, the four diagonal ones):
+                    // the first 64 candidates -- the ones that are sorted into the list -- are then the likeliest, and
+                    // few of the later ones beat the k-th of them
+                    if (r == 1 && ny == 3 && z1 - z0 == 2) row = (uint32_t)((0x862071534ull >> (4u * row)) & 15ull);
+                    const uint32_t qz_i = row / (uint32_t)ny;
+                    const int rz = z0 + (int)qz_i, ry = y0 + (int)(row - qz_i * (uint32_t)ny);
+                    const double dz = slab_gap(z, loz, rz, h, margin), dy = slab_gap(y, loy, ry, h, margin);
+                    const double rem = tau_d * inv_bs - dz * dz - dy * dy;  // (+inf while fewer than k are known)
+                    const bool inner = (ry >= py0) & (ry <= py1) & (rz >= pz0) & (rz <= pz1);
+                    if (rem >= 0.0 && (seg == 0u || inner)) {
+                        int xs = seg == 0u ? x0 : px1 + 1, xe = seg == 0u ? (inner ? px0 - 1 : x1) : x1;
+                        if (xs <= xe) {
+                            double lo_c = (double)xs, hi_c = (double)xe;
+                            if (rem < PCR_INF) {  // the chord the ball cuts out of the row, a cell of slack either side
+                                const double w = ball_half_width(rem) + margin;
+                                const double lo_f = (x - w - lox) * inv_h - 1.0, hi_f = (x + w - lox) * inv_h + 1.0;
+                                lo_c = fmin(fmax(lo_f, (double)xs), (double)xe + 1.0);
+                                hi_c = fmax(fmin(hi_f, (double)xe), (double)xs - 1.0);
+                            }
+                            xs = (int)lo_c;
+                            xe = (int)hi_c;
+                            if (xs <= xe) {
+                                const size_t base = ((size_t)rz * gy + ry) * gx;
+                                p = cs[base + xs];
+                                count = cs[base + xe + 1] - p;
+                            }
+                        }
+                    }
+                }
+                const uint32_t incl = wave_incl_scan(count);
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                if (total == 0u) continue;
+                __builtin_amdgcn_wave_barrier();
+                lds[lane] = incl - count;  // where the lane's range starts in the shell's candidate stream
+                lds[64 + lane] = p;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (uint32_t cbase = 0; cbase < total; cbase += 64u) {
+                    // ---- every lane: one candidate of the stream
+                    RDIAG(3, 1);  // chunks
+                    RDIAG(4, min(64u, total - cbase));  // candidates
+                    const uint32_t n = cbase + (uint32_t)lane;
+                    const bool have = n < total;
+                    uint32_t j = 0;  // the last range that starts at or before n (empty ranges share their successor's start)
+#pragma unroll
+                    for (uint32_t step = 32u; step > 0u; step >>= 1)
+                        if (lds[j + step] <= n) j += step;
+                    double d = PCR_INF;
+                    uint32_t ci = PCR_NO_INDEX;
+                    if (have) {
+                        const Pt4 c = pts[lds[64 + j] + (n - lds[j])];
+                        d = sqdist3(x, y, z, c.x, c.y, c.z);
+                        ci = (uint32_t)c.w;
+                    }
+                    // ---- the first 64 candidates (for most points: everything the 3x3x3 cells hold) are SORTED across the
+                    // lanes -- a bitonic network, 21 compare-exchange steps -- and the first k of them are the list
+                    if (empty) {
+                        empty = false;
+                        bitonic_stage<2, 1>(d, ci, lane);
+                        bitonic_stage<4, 2>(d, ci, lane);
+                        bitonic_stage<8, 4>(d, ci, lane);
+                        bitonic_stage<16, 8>(d, ci, lane);
+                        bitonic_stage<32, 16>(d, ci, lane);
+                        bitonic_stage<64, 32>(d, ci, lane);
+                        Ld = lane < k ? d : PCR_INF;
+                        Li = lane < k ? ci : PCR_NO_INDEX;
+                        tau_d = wave_bcast(Ld, k - 1);
+                        tau_i = wave_bcast(Li, k - 1);
+                        continue;
+                    }
+                    // ---- later ones that beat the k-th best enter the list, one at a time
+                    bool pend = have & better(d, ci, tau_d, tau_i);
+                    for (;;) {
+                        const unsigned long long m = __ballot(pend);
+                        if (!m) break;
+                        RDIAG(5, 1);  // insertions
+                        const int src = __ffsll((long long)m) - 1;
+                        const double nd = wave_bcast(d, src);
+                        const uint32_t ni = wave_bcast(ci, src);
+                        const bool lt = (lane < k) & better(nd, ni, Ld, Li);  // true from the new one's rank upwards
+                        const unsigned long long lm = __ballot(lt);
+                        const double up_d = lane_below(Ld);
+                        const uint32_t up_i = lane_below(Li);
+                        const bool lt_prev = lane > 0 && ((lm >> (lane - 1)) & 1ull);
+                        Ld = lt ? (lt_prev ? up_d : nd) : Ld;
+                        Li = lt ? (lt_prev ? up_i : ni) : Li;
+                        tau_d = wave_bcast(Ld, k - 1);
+                        tau_i = wave_bcast(Li, k - 1);
+                        pend = pend & (lane != src) & better(d, ci, tau_d, tau_i);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();  // (the ranges are overwritten by the next group of rows)
+            }
+            // ---- can anything outside the scanned box still matter? (grid_search's rule)
+            const bool all = (x0 == 0) & (x1 == gx - 1) & (y0 == 0) & (y1 == gy - 1) & (z0 == 0) & (z1 == gz - 1);
+            if (all) break;
+            double b2 = box_bound2(g, x, y, z, margin, ox2, oy2, oz2, x0, x1, y0, y1, z0, z1);
+            b2 *= bound_scale;
+            if (tau_d < b2) break;
+            px0 = x0;
+            px1 = x1;
+            py0 = y0;
+            py1 = y1;
+            pz0 = z0;
+            pz1 = z1;
+            if (r >= rmax) break;
+        }
+    }
+    // ---- the statistic (:96-118): the neighbours below MSD, a prefix of the ascending list, added NEAREST FIRST as the
+    // reference adds them (the sums are not divided -- :113-115 -- so they are large, and what is returned is a difference
+    // of two such statistics: another order of the same terms shows at 1e-9 relative on clouds in metres).  The lanes
+    // that hold the members park their points in the wave's LDS by rank; lanes 0..2 add a coordinate each, in order.
+    const bool member = (lane < k) & (Li != PCR_NO_INDEX) & (Ld < msd);
+    const int cnt = __popcll(__ballot(member));
+    double *ldsd = (double *)lds;
+    __builtin_amdgcn_wave_barrier();
+    if (member) {
+        const Pt4 q = pts[pos_of[Li]];
+        ldsd[lane * 3] = q.x;
+        ldsd[lane * 3 + 1] = q.y;
+        ldsd[lane * 3 + 2] = q.z;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double acc = lane == 0 ? x : (lane == 1 ? y : z);
+    if (lane < 3)
+        for (int j = 0; j < cnt; ++j) acc += ldsd[j * 3 + lane];
+    __builtin_amdgcn_wave_barrier();
+    double c0 = wave_bcast(acc, 0);
+    const double c1 = wave_bcast(acc, 1), c2 = wave_bcast(acc, 2);
+    const double den = (double)(cnt + 1);
+    c0 /= den;
+    c0 /= den;
+    c0 /= den;
+    return sqdist3(x, y, z, c0, c1, c2);
+}
+
+// four waves per block, a pair per wave: target side first, as the reference does (:74-75)
+__global__ void __launch_bounds__(256) reject_stat_wave_kernel(MultiView src, MultiView tgt, const double *__restrict__ pp,
+                                                               const double *__restrict__ pq, const uint32_t *__restrict__ order,
+                                                               uint32_t P, int k, double msd, double *__restrict__ d_out) {
+    __shared__ __align__(8) uint32_t lds_all[4][192];  // per wave: 128 words of ranges, later 32 x 3 doubles of neighbours
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + wave));
+    if (t >= P) return;
+    const uint32_t i = order ? (uint32_t)__builtin_amdgcn_readfirstlane((int)order[t]) : t;
+    uint32_t *lds = lds_all[wave];
+    const double s_tgt = wave_sq_dist_to_centroid(tgt.v[0], tgt.pos_of, pq[(size_t)i * 3], pq[(size_t)i * 3 + 1], pq[(size_t)i * 3 + 2],
+                                                  k, msd, lds);
+    const double s_src = wave_sq_dist_to_centroid(src.v[0], src.pos_of, pp[(size_t)i * 3], pp[(size_t)i * 3 + 1], pp[(size_t)i * 3 + 2],
+                                                  k, msd, lds);
+    if ((threadIdx.x & 63u) == 0u) d_out[i] = fabs(s_tgt - s_src);  // (:77)
+}
+
 // brute-force flavour for BRUTE indices: one lane per pair, plain global scan (small clouds only)
 template <int KC>
 __device__ __forceinline__ double sq_dist_to_centroid_brute(const MultiView &g, double x, double y, double z, int k,
@@ -244,7 +523,13 @@ static int reject_impl(pcr_ctx *ctx, const pcr_index *src, const pcr_index *tgt,
             hipLaunchKernelGGL(reject_stat_brute_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, src->view,         \
                                tgt->view, (const double *)pp_d, (const double *)pq_d, Pw, (int)msn, msd, d_d);      \
     } while (0)
-        if (Pw) {
+        const bool wave_kernel = src->kind == PCR_INDEX_GRID && src->view.levels == 1 && tgt->view.levels == 1 && msn > 8 &&
+                                 g_tune[7] != 1;
+        if (Pw && wave_kernel) {
+            ProfScope ps(ctx, PCR_PROF_KNN);
+            hipLaunchKernelGGL(reject_stat_wave_kernel, dim3((Pw + 3u) / 4u), dim3(256), 0, ctx->stream, src->view, tgt->view,
+                               (const double *)pp_d, (const double *)pq_d, qorder, Pw, (int)msn, msd, d_d);
+        } else if (Pw) {
             ProfScope ps(ctx, PCR_PROF_KNN);  // (timed with the K-NN class: two K = MSN searches per pair)
             if (msn <= 4)
                 LAUNCH_STAT(4);
@@ -321,3 +606,14 @@ extern "C" int pcr_reject_centroid_dist_sharded(pcr_ctx *ctx, const pcr_index *s
     PCR_REQUIRE(reduce, "pcr_reject_centroid_dist_sharded: NULL reduction hook");
     return reject_impl(ctx, src, tgt, pair_p, pair_q, P, msn, msd, cdf, out_keep, out_d, out_stat, reduce, reduce_user);
 }
+
+#ifdef PCR_REJ_DIAG
+extern "C" int pcr_diag_read_reject(unsigned long long out[8], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcr::g_rej_diag), sizeof(unsigned long long) * 8) != hipSuccess) return -2;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pcr::g_rej_diag), z, sizeof z) != hipSuccess) return -2;
+    }
+    return 0;
+}
+#endif
