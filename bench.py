@@ -360,7 +360,11 @@ def main():
                     comm.allreduce_partials(part_ptr)
                 elif rehearse and os.environ.get("PCR_BENCH_GLOO_DEVICE") == "1":  # (diagnostic: the route that stalled)
                     dist.all_reduce(part_t)
-                elif rehearse:  # gloo on a HOST tensor: its device-tensor path stalls now and then when two ranks share a GPU
+                elif rehearse:
+                    # gloo on a HOST tensor.  Its device-tensor path stalls now and then when two processes share one GPU:
+                    # ProcessGroupGloo's worker thread spins in hipStreamSynchronize on its pool stream behind the staging
+                    # copy while this library's stream is idle -- reproduced with nothing of this repository loaded
+                    # (tools/repro_gloo_device_stall.py; stacks in profiles/r3_gloo_device_stall.txt)
                     host = part_t.cpu()
                     dist.all_reduce(host)
                     part_t.copy_(host)

@@ -4,8 +4,10 @@
 // enqueued on the context's stream between the fused step and the solve, so the device-resident loop
 // (pcr_fit_*) never involves the host.  RCCL is bound at run time (dlopen): libpcr.so has no link-time
 // dependency on it, and inside a PyTorch process the copy PyTorch already loaded is the one that gets used.
-// Callers that already own a communicator (torch.distributed's "nccl" backend IS RCCL on ROCm) can keep using
-// it instead: all-reduce pcr_fit_partials_d() themselves -- bench.py does exactly that.
+// bench.py --gpus N uses exactly this (pcr_allreduce_partials on the kernels' stream; torch.distributed only carries the
+// unique id to the ranks).  Callers that already own a communicator (torch.distributed's "nccl" backend IS RCCL on
+// ROCm) can use that instead: all-reduce pcr_fit_partials_d() themselves -- bench.py's agreed fallback when RCCL cannot
+// be bound on every rank, and what its gloo rehearsal on a one-GPU box does.
 #include <dlfcn.h>
 #include <string.h>
 #include "pcr_internal.h"

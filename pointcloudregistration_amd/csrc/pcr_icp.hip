@@ -7,9 +7,10 @@
 //   forward K-NN, reverse 1-NN, two gates, push_back; later 5 more passes for centroids and H.
 // Here: ONE kernel per iteration in which each lane owns a sample and does
 // transform -> forward K-NN (target grid) -> reverse 1-NN (source grid; candidates moved by (R,T) as they are read: no
-// transformed copy of the source exists) -> gates -> masked fp64 accumulation, followed by a block reduction through
-// LDS; the kernel's last blocks fold the block partials in a fixed order (bitwise reproducible run to run) and, in a
-// device-resident fit on one GPU, run the 3x3 solve and the convergence criteria on the spot.
+// transformed copy of the source exists) -> gates -> masked fp64 accumulation, followed by a reduction per WAVE (a tile
+// of 64 samples) through LDS; the waves that draw the last tickets fold the tile partials in a fixed order (bitwise
+// reproducible run to run) and, in a device-resident fit on one GPU, run the 3x3 solve and the convergence criteria on
+// the spot.
 #include <math.h>
 #include <string.h>
 #include <mutex>

@@ -1,6 +1,6 @@
 """GPU parity of the device-resident fit loop (pcr_fit_*): solve, composition and convergence criteria run on the
-device, nothing leaves it between iterations.  Checked against the golden trajectories (reference tree + oracle
-loop) and, bit for bit, against the host path (pcr_icp_step_d + pcr_solve_rigid), which shares its source."""
+device, nothing leaves it between iterations.  Checked against the golden trajectories (the oracle's restatement of the
+reference's tree and loop, tests/golden/make_golden.py) and, bit for bit, against the host path (pcr_icp_step_d + pcr_solve_rigid), which shares its source."""
 import numpy as np
 import pytest
 

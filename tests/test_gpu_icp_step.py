@@ -1,5 +1,6 @@
-"""GPU parity: one ICRP iteration through the C ABI vs the golden vectors (indices produced by the
-reference's own KD-tree) and vs the oracle."""
+"""GPU parity: one ICRP iteration through the C ABI vs the golden vectors (indices produced by the ORACLE's restatement
+of the reference's KD-tree, tests/golden/make_golden.py: nothing of the reference builds here, "parity unpinned") and vs
+the oracle run live."""
 import numpy as np
 import pytest
 

@@ -173,6 +173,34 @@ def test_centroid_rejection_nested_equals_flat_equals_oracle(pcr, ctx, oracle, s
         assert (a["keep"] == want["keep"]).mean() > 0.9999   # a pair exactly on the tolerance may flip with the sum order
 
 
+def test_wave_rejection_kernel_equals_lane_kernel(pcr, ctx, oracle):
+    """On single-level grids CRejectionCentroidDist's searches run one WAVE per search (reject_stat_wave_kernel); pcr_tune
+    key 7 = 1 forces the lane-per-search kernel on the same indices: statistic, mean, sigma and mask bit for bit, on pairs
+    at a coarse alignment (the source-side query lies cells off the surface) and at the true one."""
+    from pointcloudregistration_amd import synth
+    src, tgt, Rt, tt = synth.registration_pair(80000, 70000, 17)
+    six, tix = pcr.Index(ctx, pcr.Cloud(ctx, src)), pcr.Index(ctx, pcr.Cloud(ctx, tgt))
+    U = tix.unique_sq_dist()
+    for R, T in (synth.coarse_initial_transform(Rt, tt, 80000), (synth.colmajor(Rt), tt)):
+        st = pcr.icp_step(ctx, six, tix, R, T, 4, U * 36.0, U * 4.0, exact=True)
+        kp = st["keep"].astype(bool)
+        pp, pq = oracle.transform(src, R, T)[kp], tgt[st["fwd"][kp]]
+        assert len(pp) > 10000
+        for msn in (25, 9, 32):
+            got = []
+            for mode in (0, 1):
+                try:
+                    pcr.lib().pcr_tune(7, mode)
+                    got.append(pcr.reject_centroid_dist(ctx, six, tix, pp, pq, msn=msn, msd=1.0, cdf=1.0))
+                finally:
+                    pcr.lib().pcr_tune(7, 0)
+            a, b = got
+            assert (a["d"] == b["d"]).all() and (a["keep"] == b["keep"]).all(), msn
+            assert a["mean"] == b["mean"] and a["sigma"] == b["sigma"] and 0 < a["kept"] < len(pp), msn
+    six.close()
+    tix.close()
+
+
 def test_sharded_centroid_rejection_equals_whole(pcr, oracle):
     """pcr_reject_centroid_dist_sharded (the second exchange): the pairs split over two "ranks" -- two
     threads, a context each, sharing the indices; the reduction hook sums the 17-double exchange buffers of both through
