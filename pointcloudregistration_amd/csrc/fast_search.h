@@ -31,6 +31,10 @@ constexpr uint32_t KEY_DIST_MASK = 0xFFFFF000u;  // 20 bits of distance; 12 bits
 __device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b) { return __builtin_elementwise_add_sat(a, b); }
 __device__ __forceinline__ uint32_t sat_sub(uint32_t a, uint32_t b) { return __builtin_elementwise_sub_sat(a, b); }
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// lanes 2i and 2i+1 swap a register (DPP quad_perm:[1,0,3,2]); every lane of the wave must be executing
+__device__ __forceinline__ uint32_t quad_swap1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);
+}
 // float -> u32, truncating and SATURATING (what v_cvt_u32_f32 does; a C cast is undefined beyond the range)
 __device__ __forceinline__ uint32_t cvt_u32_sat(float v) {
     uint32_t r;
@@ -168,13 +172,16 @@ struct StageClock {
 // payload, a query far outside the grid, an unresolved near-tie): the caller runs lane_search instead.
 // TRIES, U: see phase 2 (U: shadow records per trip).  RS: lanes per row of `rowtab` (ring1_pruned).  GV, RG: GridView and Rigid in whatever address space the caller keeps them (the step kernel: the constant one,
 // so that every field is a scalar load at its point of use).
-template <int KC, bool XF, bool SEEDED, int TRIES = 1, int U = PCR_FAST_U, int RS = PCR_ROW_STRIDE, class GV, class RG>
+//   PAIR       the call is made by ALL 64 lanes of a wave together (`active`: this lane has a query): phase 3's gathers are
+//              then shared by lane pairs -- see there
+template <int KC, bool XF, bool SEEDED, int TRIES = 1, int U = PCR_FAST_U, int RS = PCR_ROW_STRIDE, bool PAIR = false, class GV, class RG>
 __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ exact_pts, double qx, double qy,
                                            double qz, double sx, double sy, double sz, double max_d2, double bound_d2,
                                            double bound_scale, double extra_margin, uint32_t delta, int k,
                                            double seed_d, uint32_t seed_i, double &out_d, uint32_t &out_i,
                                            uint2 *rowtab, const RG *xf, FastExact<KC> *all = nullptr,
-                                           StageClock *clk = nullptr, Pt4 *win = nullptr, uint32_t *win_pos = nullptr) {
+                                           StageClock *clk = nullptr, Pt4 *win = nullptr, uint32_t *win_pos = nullptr,
+                                           bool active = true) {
     constexpr int KP = KC + 2;
     const uint32_t *__restrict__ cs = g.cs;
     const uint2 *__restrict__ shadow = g.shadow;
@@ -191,7 +198,7 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
     // (a literal zero margin -- every forward search -- folds away at compile time)
     const float eps = extra_margin == 0.0 ? g.key_eps : g.key_eps + (float)(extra_margin * g.key_sc) * 1.0001f;
     // key_delta holds for queries within 4 cells of the box of the points (NaN fails every comparison)
-    bool ok = (Qx >= -4.0f * KEY_CELL) & (Qx <= g.key_ext[0] + 4.0f * KEY_CELL) & (Qy >= -4.0f * KEY_CELL) &
+    bool ok = active & (Qx >= -4.0f * KEY_CELL) & (Qx <= g.key_ext[0] + 4.0f * KEY_CELL) & (Qy >= -4.0f * KEY_CELL) &
               (Qy <= g.key_ext[1] + 4.0f * KEY_CELL) & (Qz >= -4.0f * KEY_CELL) & (Qz <= g.key_ext[2] + 4.0f * KEY_CELL);
     // squared gaps -> keys, rounded down; bound_scale (< 1) as in ring1_pruned
     const float ksc = (float)bound_scale * 0.999999f;
@@ -394,8 +401,40 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
             const uint32_t base = rowtab[((key >> 8) & 15u) * RS].x;
             cpos[j] = key != KEY_SENTINEL ? base + (key & 255u) : 0u;
         }
+        if constexpr (PAIR) {
+            // A 32-byte record fetched by one lane is two 16-byte loads, and the 64 lanes of each of them ask for 64
+            // different cache lines: the most expensive requests this search makes of the L1.  Lane pairs (2i, 2i+1)
+            // share the work instead: the first load fetches the EVEN lane's record -- the even lane its lower half,
+            // the odd lane the upper half -- the second the odd lane's: the same two instructions, each touching half
+            // as many lines with neighbouring lanes on neighbouring addresses; a swap within the pair (DPP quad_perm,
+            // no LDS) hands each lane the half its partner fetched for it.  MEASURED: no gain (the 1 M x 1 M step 129.3 / 130.5
+            // us with, 128.4 / 128.9 without) -- what these gathers cost the L1 is not a matter of lines per instruction;
+            // the step kernel leaves it off (PCR_FAST_PAIR).
+            const uint32_t odd = threadIdx.x & 1u;
+            const u32x4 *__restrict__ halves = (const u32x4 *)exact_pts;
+            u32x4 ha[KC], hb[KC];
 #pragma unroll
-        for (int j = 0; j < KC; ++j) crec[j] = exact_pts[cpos[j]];
+            for (int j = 0; j < KC; ++j) {
+                const uint32_t theirs = quad_swap1(cpos[j]);
+                const uint32_t pos_even = odd ? theirs : cpos[j], pos_odd = odd ? cpos[j] : theirs;
+                ha[j] = halves[2u * (size_t)pos_even + odd];
+                hb[j] = halves[2u * (size_t)pos_odd + odd];
+            }
+#pragma unroll
+            for (int j = 0; j < KC; ++j) {
+                u32x4 got;  // what the partner fetched for this lane: the even lane sends hb, the odd lane ha
+#pragma unroll
+                for (int c = 0; c < 4; ++c) got[c] = quad_swap1(odd ? ha[j][c] : hb[j][c]);
+                const u32x4 lo = odd ? got : ha[j], hi = odd ? hb[j] : got;
+                crec[j].x = __builtin_bit_cast(double, ((unsigned long long)lo[1] << 32) | lo[0]);
+                crec[j].y = __builtin_bit_cast(double, ((unsigned long long)lo[3] << 32) | lo[2]);
+                crec[j].z = __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | hi[0]);
+                crec[j].w = ((unsigned long long)hi[3] << 32) | hi[2];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < KC; ++j) crec[j] = exact_pts[cpos[j]];
+        }
 #pragma unroll
         for (int j = 0; j < KC; ++j) {
             const double dd = cand_d2<XF, RG>(xf, qx, qy, qz, crec[j]);

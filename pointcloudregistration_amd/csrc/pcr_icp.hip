@@ -600,6 +600,13 @@ __device__ PCR_FALLBACK_INLINE uint32_t fallback_reverse(const StepArgs *__restr
     return rt.idx[0];
 }
 
+#ifndef PCR_FAST_PAIR
+#define PCR_FAST_PAIR 0  // phase 3's fp64 gathers shared by lane pairs (fast_search.h): measured 129.3 / 130.5 us against
+                         // 128.4 / 128.9 without, same box, alternating runs -- off
+#endif
+#ifndef PCR_FAST_TRIES_FWD
+#define PCR_FAST_TRIES_FWD 1
+#endif
 #ifndef PCR_FAST_U_FWD
 #define PCR_FAST_U_FWD 8  // shadow records per trip of the forward / reverse search (fast_search.h: PCR_FAST_U)
 #endif
@@ -675,10 +682,17 @@ __device__ __forceinline__ void fast_tile(const StepArgs *__restrict__ Ap, uint3
             const float s2 = (a + b) * 1.0000005f;
             bound_d2 = (double)(s2 * s2) * 1.000001;  // inf stays inf
         }
-        if (fin)  // NeighborSet.back() = K-th nearest (:91-92)
-            fwd_done = fast_ring1<KC, false, false, 1, PCR_FAST_U_FWD, FAST_RS>(GT, GT.pts, px, py, pz, px, py, pz, fmax_d2, bound_d2,
-                                                                            fwd_scale, 0.0, GT.key_delta, A->k, 0.0, 0u, dF, j,
-                                                                            my_rows, (const Rigid *)nullptr, &fx, pf, nullptr, &qpos);
+        // NeighborSet.back() = K-th nearest (:91-92).  Called by the whole wave (lanes without a sample take no part in
+        // phases 1-2 and help their partners in phase 3: fast_search.h, PAIR)
+        fwd_done = fast_ring1<KC, false, false, PCR_FAST_TRIES_FWD, PCR_FAST_U_FWD, FAST_RS, PCR_FAST_PAIR != 0>(
+            GT, GT.pts, px, py, pz, px, py, pz, fmax_d2, bound_d2, fwd_scale, 0.0, GT.key_delta, A->k, 0.0, 0u, dF, j, my_rows,
+            (const Rigid *)nullptr, &fx, pf, nullptr, &qpos, fin);
+        if (!fin) {
+            fwd_done = true;
+            dF = fmax_d2;
+            j = PCR_NO_INDEX;
+            fx.trusted = false;
+        }
         q_known = fin & fwd_done & (qpos != PCR_NO_INDEX);  // the walk hands over q's position with its index
         if (__any(!fwd_done)) {
             if (!fwd_done) fallback_forward<KC>(Ap, px, py, pz, fmax_d2, fwd_scale, A->k, my_rows, &dF, &j, fin ? &fx : nullptr);
@@ -719,10 +733,20 @@ __device__ __forceinline__ void fast_tile(const StepArgs *__restrict__ Ap, uint3
         double dRv = dF;  // the reverse winner's distance to q (not used further) and index
         uint32_t rv = orig;
         Pt4 srec = {0.0, 0.0, 0.0, 0ull};
-        if (rev_active)
-            rev_done = fast_ring1<1, true, true, 1, PCR_FAST_U_REV, FAST_RS>(GS, GS.pts, qx, qy, qz, sx, sy, sz, PCR_INF, dF, rbs, rem_,
-                                                                         rev_delta, 1, dF, orig, dRv, rv, my_rows, &D->M, nullptr, pr,
-                                                                         &srec);
+        {
+            double dRv_ = dF;
+            uint32_t rv_ = orig;
+            Pt4 srec_;
+            const bool done_ = fast_ring1<1, true, true, 1, PCR_FAST_U_REV, FAST_RS, PCR_FAST_PAIR != 0>(
+                GS, GS.pts, qx, qy, qz, sx, sy, sz, PCR_INF, dF, rbs, rem_, rev_delta, 1, dF, orig, dRv_, rv_, my_rows, &D->M,
+                nullptr, pr, &srec_, nullptr, rev_active);
+            if (rev_active) {
+                rev_done = done_;
+                dRv = dRv_;
+                rv = rv_;
+                srec = srec_;
+            }
+        }
         const bool s_known = rev_active & rev_done;
         if (__any(!rev_done)) {
             if (!rev_done) rv = fallback_reverse(Ap, qx, qy, qz, sx, sy, sz, rbs, rem_, dF, orig, my_rows);
@@ -1404,9 +1428,14 @@ int pcr_icp_step_noalloc_d(pcr_ctx *ctx, const pcr_index *src, const pcr_index *
     // otherwise poison every later call on this GPU: clear them here, stream-ordered, every call -- with a tiny kernel
     // (allocates nothing, and is an ordinary kernel node under stream capture).
     hipLaunchKernelGGL(fill_u32_kernel, dim3(1), dim3(256), 0, ctx->stream, S->tickets, (uint32_t)(sizeof S->tickets / 4), 0u);
-    return step_enqueue(ctx, src, tgt, sample_idx_d, sample_begin, m, R, T, k, thr_fwd_sq, thr_rev_sq, flags, partials_d,
-                        out_fwd_d, out_rev_d, out_keep_d, &S->step, S->group_partials, S->tickets, S->block_partials,
-                        "pcr_icp_step_noalloc_d");
+    // (the context's event profiler creates its events on first use: not inside this call)
+    const bool profiling = ctx->profiling;
+    ctx->profiling = false;
+    const int rc = step_enqueue(ctx, src, tgt, sample_idx_d, sample_begin, m, R, T, k, thr_fwd_sq, thr_rev_sq, flags,
+                                partials_d, out_fwd_d, out_rev_d, out_keep_d, &S->step, S->group_partials, S->tickets,
+                                S->block_partials, "pcr_icp_step_noalloc_d");
+    ctx->profiling = profiling;
+    return rc;
 }
 
 // test hook (not in include/pcr.h): leaves this GPU's fixed tickets non-zero, as a launch that died mid-fold would
