@@ -519,6 +519,7 @@ def main():
                                                    "(profiles/), which is why this figure -- not kernel_ms_avg -- matches the "
                                                    "profile's average; tools/bench_graph.py measures the difference",
                          "kernel_ms_first_iteration": float(per_launch[0]) if len(per_launch) else None,
+                         "kernel_ms_per_iteration": [round(float(x), 5) for x in per_launch],
                          "prewarm_steps": args.prewarm_steps,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "other_kernels_ms_avg": {"transform": kt_warm["transform"][0] / max(1, kt_warm["transform"][1]),

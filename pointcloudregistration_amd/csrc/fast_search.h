@@ -383,8 +383,18 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
     };
     // exact squared distance every candidate with a key >= `key` is at least at
     const double floor_sc = g.key_invS * (1.0 - 9.313225746154785e-10);  // (uniform: one product, not one per call)
+    // The bound by DISTANCE, not the worst case over the key range: a key is the squared length of an integer vector that
+    // differs from the exact one by at most one unit per axis (the point's rounding and the query's: pcr_core.hip), so
+    // |key - exact| <= 2 sqrt(3) * 1.01 * sqrt(exact) + 3.1 -- and a candidate whose exact value is BELOW its (truncated)
+    // key has sqrt(exact) < sqrt(key).  `delta` is that bound at the largest distance of interest (plus, for the reverse
+    // search, what the caller added for R's deviation from an isometry and the inverse map's rounding: kept as it is);
+    // at a typical K-th distance of half a cell the bound by distance is a third of it, and the verification below fails
+    // a third as often (a wave runs the second stage when ANY lane's fails: 67 % -> 28 % of the waves of a 1 M x 1 M step).
+    const uint32_t delta_extra = delta - min(delta, g.key_delta);
     auto floor_d2 = [&](uint32_t key) {
-        return key == KEY_SENTINEL ? PCR_INF : (double)sat_sub(key & KEY_DIST_MASK, delta) * floor_sc;
+        const uint32_t km = key & KEY_DIST_MASK;
+        const uint32_t by_dist = (uint32_t)(sqrtf((float)km) * 3.4995f) + 72u + delta_extra;  // (3.4988 rounded up past fp32's roundings)
+        return key == KEY_SENTINEL ? PCR_INF : (double)sat_sub(km, min(by_dist, delta)) * floor_sc;
     };
     if constexpr (SEEDED) {
         ed[0] = seed_d;
