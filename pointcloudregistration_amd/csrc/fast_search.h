@@ -297,6 +297,8 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
     DIAG_LANE_ADD(17 + 4 * XF, ok ? 0 : 1);           // ... that cannot start (far query, long row)
     while (alive) {
         DIAG_ADD(24 + XF, 1);  // wave trips
+        DIAG_LANE_ADD(36 + XF, 1);                                   // ... lane trips (the wave's are the slowest lane's)
+        DIAG_LANE_ADD(38 + XF, (e == p) ? 1 : 0);                    // ... of which with nothing left of the current row
         const uint32_t rem = e - p;
         uint32_t p2 = 0, e2 = 0, pb2 = 0;
         // open the next row when the current one cannot fill the trip; a row that turns out to be pruned as a whole
@@ -356,6 +358,7 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
             asm volatile("" : "+v"(key));  // computed in every lane, selected below: no branch per slot
             T.insert((((uint32_t)u < totE) & ((uint32_t)u != dummy)) ? key : KEY_SENTINEL);
         }
+        DIAG_LANE_ADD(40 + XF, min(totE, (uint32_t)U));  // slots that held a candidate (or a dummy)
         alive = (p < e) | (ri < cnt);
     }
     STAGE_CLOCK(clk, 2);

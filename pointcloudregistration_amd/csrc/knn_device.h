@@ -17,7 +17,7 @@ namespace pcr {
 
 #ifdef PCR_DIAG
 // diagnostic build only (libpcr_diag.so): counters of the lane search.  Never compiled into libpcr.so.
-static __device__ unsigned long long g_diag[32];
+static __device__ unsigned long long g_diag[48];  // (32..47: the filtered step kernel's own, pcr_icp.hip)
 #define DIAG_T() ((unsigned long long)__builtin_amdgcn_s_memtime())
 #define DIAG_ADD(slot, v)                                                                \
     do {                                                                                 \

@@ -566,16 +566,42 @@ __global__ void __launch_bounds__(QS_THREADS) qsort_hist_kernel(const double *__
     __syncthreads();
     const uint32_t first = blockIdx.x * QS_TILE;
     const uint32_t last = min(first + (uint32_t)QS_TILE, nq);
-    for (uint32_t i = first + threadIdx.x; i < last; i += QS_THREADS) {
-        const uint32_t k = qsort_key(Q, q, i);
-        keys[i] = (uint16_t)k;
-        atomicAdd(&hist[k], 1u);
+    constexpr int PER = QS_TILE / QS_THREADS;
+    {
+        // a thread's PER queries: all coordinate loads in flight together, then the keys
+        uint32_t k[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const uint32_t i = first + threadIdx.x + (uint32_t)u * QS_THREADS;
+            k[u] = i < last ? qsort_key(Q, q, i) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const uint32_t i = first + threadIdx.x + (uint32_t)u * QS_THREADS;
+            if (k[u] != 0xFFFFFFFFu) {
+                keys[i] = (uint16_t)k[u];
+                atomicAdd(&hist[k[u]], 1u);
+            }
+        }
     }
     __syncthreads();
+    // The block's share of every bucket it touched: one returning atomic per bucket -- consecutive lanes, consecutive
+    // buckets -- and ALL of a thread's atomics in flight before the first result is stored: a loop that stores each result
+    // before issuing the next atomic is a chain of QS_MAX_BUCKETS / QS_THREADS round trips to the L2 (that chain WAS this
+    // kernel's 16 us per 1 M queries).
     uint32_t *row = basemat + (size_t)blockIdx.x * Q.buckets;
-    for (uint32_t b = threadIdx.x; b < Q.buckets; b += QS_THREADS) {
-        const uint32_t c = hist[b];
-        row[b] = c ? atomicAdd(&totals[b], c) : 0u;  // consecutive lanes, consecutive buckets
+    constexpr int NB = QS_MAX_BUCKETS / QS_THREADS;
+    uint32_t got[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const uint32_t b = threadIdx.x + (uint32_t)u * QS_THREADS;
+        const uint32_t c = b < Q.buckets ? hist[b] : 0u;
+        got[u] = c ? atomicAdd(&totals[b], c) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const uint32_t b = threadIdx.x + (uint32_t)u * QS_THREADS;
+        if (b < Q.buckets) row[b] = got[u];
     }
 }
 
@@ -588,8 +614,19 @@ __global__ void __launch_bounds__(QS_THREADS) qsort_scatter_kernel(const uint16_
     // exclusive scan of the bucket totals: each thread owns a contiguous run of buckets
     const uint32_t per = (Q.buckets + QS_THREADS - 1) / QS_THREADS;
     const uint32_t b0 = threadIdx.x * per, b1 = min(b0 + per, Q.buckets);
+    // (fixed trip counts and every load issued before the first use: a run-time bound makes each load wait for the last)
+    constexpr int NB = QS_MAX_BUCKETS / QS_THREADS;
+    const uint32_t *row = basemat + (size_t)blockIdx.x * Q.buckets;
+    uint32_t tot[NB], mine[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const uint32_t b = b0 + (uint32_t)u;
+        tot[u] = b < b1 ? totals[b] : 0u;
+        mine[u] = b < b1 ? row[b] : 0u;
+    }
     uint32_t sum = 0;
-    for (uint32_t b = b0; b < b1; ++b) sum += totals[b];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) sum += tot[u];
     // block-wide exclusive scan of the per-thread sums: shuffles inside a wave, then the 16 wave totals
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t incl = sum;
@@ -605,16 +642,28 @@ __global__ void __launch_bounds__(QS_THREADS) qsort_scatter_kernel(const uint16_
     __syncthreads();
     part[threadIdx.x] = wave_base + incl - sum;
     __syncthreads();
-    const uint32_t *row = basemat + (size_t)blockIdx.x * Q.buckets;
     uint32_t run = part[threadIdx.x];
-    for (uint32_t b = b0; b < b1; ++b) {
-        cur[b] = run + row[b];
-        run += totals[b];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const uint32_t b = b0 + (uint32_t)u;
+        if (b < b1) cur[b] = run + mine[u];
+        run += tot[u];
     }
     __syncthreads();
     const uint32_t first = blockIdx.x * QS_TILE;
     const uint32_t last = min(first + (uint32_t)QS_TILE, nq);
-    for (uint32_t i = first + threadIdx.x; i < last; i += QS_THREADS) order[atomicAdd(&cur[keys[i]], 1u)] = i;
+    constexpr int PER = QS_TILE / QS_THREADS;
+    uint32_t k[PER];  // (all key loads in flight together)
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const uint32_t i = first + threadIdx.x + (uint32_t)u * QS_THREADS;
+        k[u] = i < last ? (uint32_t)keys[i] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const uint32_t i = first + threadIdx.x + (uint32_t)u * QS_THREADS;
+        if (k[u] != 0xFFFFFFFFu) order[atomicAdd(&cur[k[u]], 1u)] = i;
+    }
 }
 
 int coarse_query_order(pcr_ctx *ctx, const GridView &g, const double *q_d, uint32_t nq, uint32_t *order_d) {

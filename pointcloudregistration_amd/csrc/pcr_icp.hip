@@ -694,6 +694,8 @@ __device__ __forceinline__ void fast_tile(const StepArgs *__restrict__ Ap, uint3
             fx.trusted = false;
         }
         q_known = fin & fwd_done & (qpos != PCR_NO_INDEX);  // the walk hands over q's position with its index
+        DIAG_ADD(32, 1);                          // (diagnostic build) waves
+        DIAG_ADD(33, __any(!fwd_done) ? 1 : 0);   // ... in which some lane's forward search goes on to the fp64 walk
         if (__any(!fwd_done)) {
             if (!fwd_done) fallback_forward<KC>(Ap, px, py, pz, fmax_d2, fwd_scale, A->k, my_rows, &dF, &j, fin ? &fx : nullptr);
         }
@@ -748,6 +750,7 @@ __device__ __forceinline__ void fast_tile(const StepArgs *__restrict__ Ap, uint3
             }
         }
         const bool s_known = rev_active & rev_done;
+        DIAG_ADD(34, __any(!rev_done) ? 1 : 0);   // ... some lane's reverse search
         if (__any(!rev_done)) {
             if (!rev_done) rv = fallback_reverse(Ap, qx, qy, qz, sx, sy, sz, rbs, rem_, dF, orig, my_rows);
         }
@@ -1919,10 +1922,10 @@ extern "C" int pcr_diag_block_times(unsigned long long *out, unsigned n) {
 }
 #endif
 #ifdef PCR_DIAG
-extern "C" int pcr_diag_read_icp(unsigned long long out[32], int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcr::g_diag), sizeof(unsigned long long) * 32) != hipSuccess) return -2;
+extern "C" int pcr_diag_read_icp(unsigned long long out[48], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcr::g_diag), sizeof(unsigned long long) * 48) != hipSuccess) return -2;
     if (reset) {
-        unsigned long long z[32] = {0};
+        unsigned long long z[48] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(pcr::g_diag), z, sizeof z) != hipSuccess) return -2;
     }
     return 0;

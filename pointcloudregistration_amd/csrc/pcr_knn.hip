@@ -287,10 +287,10 @@ int pcr_unique_sq_dist(pcr_ctx *ctx, const pcr_index *ix, double *out) {
 }  // extern "C"
 
 #ifdef PCR_DIAG
-extern "C" int pcr_diag_read_knn(unsigned long long out[32], int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcr::g_diag), sizeof(unsigned long long) * 32) != hipSuccess) return -2;
+extern "C" int pcr_diag_read_knn(unsigned long long out[48], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcr::g_diag), sizeof(unsigned long long) * 48) != hipSuccess) return -2;
     if (reset) {
-        unsigned long long z[32] = {0};
+        unsigned long long z[48] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(pcr::g_diag), z, sizeof z) != hipSuccess) return -2;
     }
     return 0;
