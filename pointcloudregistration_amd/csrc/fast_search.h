@@ -56,11 +56,13 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 // key-space integer coordinate of a cloud coordinate (the expression shadow_kernel uses: pcr_core.hip)
 __device__ __forceinline__ int key_coord(double v, double lo, double sc) { return __double2int_rn((v - lo) * sc); }
 // the squared distance, in key units, between the query (QX; Qyz = Y16 | Z16 << 16) and a shadow record: 4 instructions
+// (v_sub_u32, v_pk_sub_i16, v_mul_i32_i24, v_dot2c_i32_i16)
 __device__ __forceinline__ uint32_t shadow_key_d2(uint32_t QX, uint32_t Qyz, uint32_t rec_x, uint32_t rec_yz) {
     const int dx = (int)(QX - rec_x);
     const s16x2 dyz = __builtin_bit_cast(s16x2, Qyz) - __builtin_bit_cast(s16x2, rec_yz);  // v_pk_sub_i16, wrapping
-    const int dyz2 = __builtin_amdgcn_sdot2(dyz, dyz, 0, false);                          // v_dot2_i32_i16
-    return (uint32_t)__mul24(dx, dx) + (uint32_t)dyz2;                                     // v_mad_i32_i24
+    // (dx^2 first, the dot product accumulates onto it: v_mul_i32_i24 + v_dot2c_i32_i16 -- the other way round the
+    // accumulating form of the dot product wants a zeroed register first: one instruction more per candidate)
+    return (uint32_t)__builtin_amdgcn_sdot2(dyz, dyz, __mul24(dx, dx), false);
 }
 // One axis: the cell the key-space coordinate Q falls in (clamped to the grid), and the distances from Q to that cell's
 // low and high face, each shrunk by eps and clamped at 0.
