@@ -107,6 +107,15 @@ __device__ __forceinline__ double xor_lane(double v) {
 __device__ __forceinline__ uint32_t lane_below(uint32_t v) {  // lane l receives lane l-1's value (lane 0: 0)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
+// the same under a lane mask: a lane whose lower neighbour is outside the mask keeps its own value
+__device__ __forceinline__ uint32_t lane_below_keep(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ double lane_below_keep(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = lane_below_keep((uint32_t)b), hi = lane_below_keep((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ double lane_below(double v) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
     const uint32_t lo = lane_below((uint32_t)b), hi = lane_below((uint32_t)(b >> 32));
@@ -128,13 +137,20 @@ __device__ __forceinline__ void bitonic_stage(double &d, uint32_t &ci, int lane)
     bitonic_step<KK, JJ>(d, ci, lane);
     if constexpr (JJ > 1) bitonic_stage<KK, JJ / 2>(d, ci, lane);
 }
+// inclusive prefix sum over the 64 lanes: four DPP row shifts (zero fill) scan each row of 16, two row broadcasts carry
+// the rows' totals on -- six data-parallel moves where six __shfl_up are six trips through ds_bpermute with their
+// address arithmetic.  Every lane of the wave must be executing.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_zero(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-    const int lane = (int)(threadIdx.x & 63u);
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)v, m, 64);
-        v += lane >= m ? o : 0u;
-    }
+    v += dpp_zero<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_zero<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_zero<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_zero<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_zero<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_zero<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
     return v;
 }
 // (PCR_REJ_DIAG: a diagnostic build's counters -- searches, shells, row groups, chunks, candidates, insertions; measured
@@ -193,25 +209,42 @@ __device__ __forceinline__ double wave_sq_dist_to_centroid(const GridView &g, co
             const int y0 = max(cy - r, 0), y1 = min(cy + r, gy - 1);
             const int z0 = max(cz - r, 0), z1 = min(cz + r, gz - 1);
             const int ny = y1 - y0 + 1;
-            const uint32_t nent = 2u * (uint32_t)ny * (uint32_t)(z1 - z0 + 1);  // a row has up to two new x-segments
+            // A row of the shell has ONE new x-segment -- all of it -- unless it crosses the box scanned so far, whose rows
+            // have two (left and right of the box).  Entries: the shell's rows, then the box's rows once more for their
+            // second segment (round 3: two entries for EVERY row -- 14 groups of 64 for shells 1, 2, 4, 8 where this takes 10).
+            const int nyi = py1 >= py0 ? py1 - py0 + 1 : 0, nzi = pz1 >= pz0 ? pz1 - pz0 + 1 : 0;
+            const uint32_t nrows = (uint32_t)ny * (uint32_t)(z1 - z0 + 1);
+            const uint32_t nent = nrows + (uint32_t)nyi * (uint32_t)nzi;
+            const float inv_ny = 1.0f / (float)ny, inv_nyi = 1.0f / (float)(nyi > 0 ? nyi : 1);
             for (uint32_t ebase = 0; ebase < nent; ebase += 64u) {
                 // ---- every lane: one (row, segment) of the shell -> its range of positions
                 RDIAG(2, 1);  // entry groups
                 const uint32_t ent = ebase + (uint32_t)lane;
                 uint32_t p = 0, count = 0;
                 if (ent < nent) {
-                    uint32_t row = ent >> 1;
-                    const uint32_t seg = ent & 1u;
+                    const uint32_t seg = ent >= nrows ? 1u : 0u;
+                    uint32_t row = seg ? ent - nrows : ent;
                     // the first cube's rows nearest first (the point's own row, the four beside it, the four diagonal ones):
                     // the first 64 candidates -- the ones that are sorted into the list -- are then the likeliest, and
                     // few of the later ones beat the k-th of them
                     if (r == 1 && ny == 3 && z1 - z0 == 2) row = (uint32_t)((0x862071534ull >> (4u * row)) & 15ull);
-                    const uint32_t qz_i = row / (uint32_t)ny;
-                    const int rz = z0 + (int)qz_i, ry = y0 + (int)(row - qz_i * (uint32_t)ny);
+                    // row = qz * w + qy, w the width of whichever box the entry runs over: quotient by a float reciprocal and
+                    // one correction either way (a 32-bit integer division is two dozen instructions)
+                    const uint32_t wdt = seg ? (uint32_t)nyi : (uint32_t)ny;
+                    uint32_t qz_i = (uint32_t)(((float)row + 0.5f) * (seg ? inv_nyi : inv_ny));
+                    int qy_i = (int)row - (int)(qz_i * wdt);
+                    if (qy_i < 0) {
+                        --qz_i;
+                        qy_i += (int)wdt;
+                    } else if (qy_i >= (int)wdt) {
+                        ++qz_i;
+                        qy_i -= (int)wdt;
+                    }
+                    const int rz = (seg ? pz0 : z0) + (int)qz_i, ry = (seg ? py0 : y0) + qy_i;
                     const double dz = slab_gap(z, loz, rz, h, margin), dy = slab_gap(y, loy, ry, h, margin);
                     const double rem = tau_d * inv_bs - dz * dz - dy * dy;  // (+inf while fewer than k are known)
                     const bool inner = (ry >= py0) & (ry <= py1) & (rz >= pz0) & (rz <= pz1);
-                    if (rem >= 0.0 && (seg == 0u || inner)) {
+                    if (rem >= 0.0) {
                         int xs = seg == 0u ? x0 : px1 + 1, xe = seg == 0u ? (inner ? px0 - 1 : x1) : x1;
                         if (xs <= xe) {
                             double lo_c = (double)xs, hi_c = (double)xe;
@@ -283,12 +316,18 @@ __device__ __forceinline__ double wave_sq_dist_to_centroid(const GridView &g, co
                         const double nd = wave_bcast(d, src);
                         const uint32_t ni = wave_bcast(ci, src);
                         const bool lt = (lane < k) & better(nd, ni, Ld, Li);  // true from the new one's rank upwards
-                        const unsigned long long lm = __ballot(lt);
-                        const double up_d = lane_below(Ld);
-                        const uint32_t up_i = lane_below(Li);
-                        const bool lt_prev = lane > 0 && ((lm >> (lane - 1)) & 1ull);
-                        Ld = lt ? (lt_prev ? up_d : nd) : Ld;
-                        Li = lt ? (lt_prev ? up_i : ni) : Li;
+                        const int first = __ffsll((long long)__ballot(lt)) - 1;  // the new one's rank (it beats the k-th: >= 0)
+                        // the lanes from that rank on take their lower neighbour's entry (a DPP shift under the mask: the
+                        // lane at the rank itself reads a lane outside the mask and is overwritten next), the lane at the
+                        // rank takes the new one
+                        if (lt) {
+                            Ld = lane_below_keep(Ld);
+                            Li = lane_below_keep(Li);
+                        }
+                        if (lane == first) {
+                            Ld = nd;
+                            Li = ni;
+                        }
                         tau_d = wave_bcast(Ld, k - 1);
                         tau_i = wave_bcast(Li, k - 1);
                         pend = pend & (lane != src) & better(d, ci, tau_d, tau_i);
