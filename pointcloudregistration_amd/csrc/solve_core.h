@@ -49,15 +49,17 @@ PCR_HD inline bool jacobi_pair(double *A, double *V) {
         beta += A[J * 3 + r] * A[J * 3 + r];
         gamma += A[I * 3 + r] * A[J * 3 + r];
     }
-    // (one thread runs this, and on the device every fp64 square root or division is a dependent chain of a dozen
-    // instructions: the test is taken on squares, and t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)) with
-    // zeta = (beta - alpha) / (2 gamma) is evaluated with numerator and denominator multiplied by 2 |gamma| -- two square
-    // roots and two divisions per rotation where the textbook form has three of each)
+    // (one thread runs this, and on the device every fp64 square root or division is a dependent chain of two dozen
+    // instructions -- the rotations ARE the solve's time.  The test is taken on squares.  With d = beta - alpha,
+    // r = sqrt(d^2 + 4 gamma^2) and u = |d| + r the textbook t = sign(d) 2 gamma / u has 1 + t^2 = 2 r / u, hence
+    // c = u / w and s = sign(d) 2 gamma / w with w = sqrt(2 r u): two square roots and ONE division per rotation (round
+    // 2: two and two, the textbook three and three), and c, s come from one reciprocal instead of one after the other.)
     const double g2 = gamma * gamma;
     if (g2 <= 1.9721522630525295e-31 * (alpha * beta)) return false;  // |gamma| <= 2^-51 sqrt(alpha beta)
     const double d = beta - alpha;
-    const double t = (d >= 0 ? 2.0 * gamma : -2.0 * gamma) / (fabs(d) + sqrt(d * d + 4.0 * g2));
-    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+    const double r = sqrt(d * d + 4.0 * g2), u = fabs(d) + r;
+    const double iw = 1.0 / sqrt(2.0 * r * u);
+    const double c = u * iw, s = (d >= 0 ? 2.0 * gamma : -2.0 * gamma) * iw;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const double ai = A[I * 3 + r], aj = A[J * 3 + r];
