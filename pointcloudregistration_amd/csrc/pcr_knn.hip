@@ -63,12 +63,15 @@ __global__ void __launch_bounds__(256) knn_grid_kernel(MultiView g, const MultiV
 // decides and verifies) and, for the rare lane it cannot vouch for, the fp64 walk above.  The grid's description is
 // read from device memory through the constant address space (scalar loads at the point of use).
 #define PCR_CONST_AS __attribute__((address_space(4)))
+#ifndef PCR_KNN_BLOCK
+#define PCR_KNN_BLOCK 256  // lanes per block of the filtered K-NN kernel (1 M queries, K = 1 / 4, e9 queries/s: 64: 8.4 / 6.8, 256: 9.1 / 7.3)
+#endif
 template <int KC>
-__global__ void __launch_bounds__(256, 4) knn_fast_kernel(const MultiView *__restrict__ gp, const double *__restrict__ q,
+__global__ void __launch_bounds__(PCR_KNN_BLOCK, 4) knn_fast_kernel(const MultiView *__restrict__ gp, const double *__restrict__ q,
                                                           const uint32_t *__restrict__ order, uint32_t nq, int k, int order_out,
                                                           double max_d2, uint32_t *__restrict__ out_idx,
                                                           double *__restrict__ out_d2) {
-    const uint32_t t = xcd_remap(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
+    const uint32_t t = xcd_remap(blockIdx.x, gridDim.x) * (uint32_t)PCR_KNN_BLOCK + threadIdx.x;
     const bool live = t < nq;
     const uint32_t i = live ? (order ? order[t] : t) : 0u;
     double qx = 0, qy = 0, qz = 0;
@@ -78,7 +81,7 @@ __global__ void __launch_bounds__(256, 4) knn_fast_kernel(const MultiView *__res
         qz = q[(size_t)i * 3 + 2];
     }
     const bool active = live && isfinite(qx) && isfinite(qy) && isfinite(qz);
-    __shared__ uint2 rowtab[9][256];
+    __shared__ uint2 rowtab[9][PCR_KNN_BLOCK];
     uint2 *my_rows = &rowtab[0][threadIdx.x];
     const PCR_CONST_AS GridView &G = ((const PCR_CONST_AS MultiView *)(uintptr_t)gp)->v[0];
     const double scale = 1.0 - 1.8189894035458565e-12;
@@ -87,8 +90,8 @@ __global__ void __launch_bounds__(256, 4) knn_fast_kernel(const MultiView *__res
     uint32_t ik;
     bool done = !active;
     if (active)
-        done = fast_ring1<KC, false, false, 3, PCR_KNN_U>(G, G.pts, qx, qy, qz, qx, qy, qz, max_d2, PCR_INF, scale, 0.0, G.key_delta, k, 0.0,
-                                            0u, dk, ik, my_rows, (const Rigid *)nullptr, &ex);
+        done = fast_ring1<KC, false, false, 3, PCR_KNN_U, PCR_KNN_BLOCK>(G, G.pts, qx, qy, qz, qx, qy, qz, max_d2, PCR_INF, scale, 0.0,
+                                                                    G.key_delta, k, 0.0, 0u, dk, ik, my_rows, (const Rigid *)nullptr, &ex);
     uint32_t *oi = out_idx + (size_t)i * k;
     double *od = out_d2 ? out_d2 + (size_t)i * k : nullptr;
     if (active & done) {  // rank r of the exact candidates goes to slot r (or k-1-r): the first k ranks fill the row
@@ -107,7 +110,7 @@ __global__ void __launch_bounds__(256, 4) knn_fast_kernel(const MultiView *__res
             top.init(max_d2);
             if (active) {
                 const GridView Gc = gp->v[0];
-                lane_search<KC>(Gc, gp->all, qx, qy, qz, qx, qy, qz, max_d2, scale, 0.0, top, my_rows);
+                lane_search<KC, false, PCR_KNN_BLOCK>(Gc, gp->all, qx, qy, qz, qx, qy, qz, max_d2, scale, 0.0, top, my_rows);
             }
             write_result<KC>(top, k, order_out, max_d2, oi, od);
         }
@@ -156,8 +159,8 @@ static void launch_knn(pcr_ctx *ctx, const pcr_index *ix, const double *q_d, con
     const uint32_t nb = (nq + 255) / 256;
     if constexpr (KC <= 4) {
         if (ix->kind == PCR_INDEX_GRID && ix->view.levels == 1 && ix->view.v[0].shadow && ix->view_d && g_tune[5] != 1) {
-            hipLaunchKernelGGL(knn_fast_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, (const MultiView *)ix->view_d, q_d,
-                               qorder, nq, (int)k, order, max_d2, oi_d, od_d);
+            hipLaunchKernelGGL(knn_fast_kernel<KC>, dim3((nq + PCR_KNN_BLOCK - 1) / PCR_KNN_BLOCK), dim3(PCR_KNN_BLOCK), 0, ctx->stream,
+                               (const MultiView *)ix->view_d, q_d, qorder, nq, (int)k, order, max_d2, oi_d, od_d);
             return;
         }
     }
