@@ -732,8 +732,7 @@ __device__ __forceinline__ void fast_tile(const StepArgs *__restrict__ Ap, uint3
         const double rbs = D->rev_bound_scale, rem_ = D->rev_extra_margin;
         const uint32_t rev_delta = D->rev_delta;  // (make_dyn)
         bool rev_done = !rev_active;
-        double dRv = dF;  // the reverse winner's distance to q (not used further) and index
-        uint32_t rv = orig;
+        uint32_t rv = orig;  // the reverse winner's index
         Pt4 srec = {0.0, 0.0, 0.0, 0ull};
         {
             double dRv_ = dF;
@@ -744,7 +743,6 @@ __device__ __forceinline__ void fast_tile(const StepArgs *__restrict__ Ap, uint3
                 nullptr, pr, &srec_, nullptr, rev_active);
             if (rev_active) {
                 rev_done = done_;
-                dRv = dRv_;
                 rv = rv_;
                 srec = srec_;
             }
