@@ -255,7 +255,20 @@ __device__ __forceinline__ void wave_fold17(const double *x, size_t stride, uint
     double v[17];
 #pragma unroll
     for (int j = 0; j < 17; ++j) v[j] = 0.0;
-    for (uint32_t i = lane; i < count; i += 64u) {
+    // (two rounds of loads in flight per trip -- the loads are device-scope atomics, which the compiler keeps in program
+    // order: one round per trip is one trip to memory per 64 values of a column, and the fold of 245 groups waited for
+    // four of them; the order of the additions is unchanged)
+    uint32_t i = lane;
+    for (; i + 64u < count; i += 128u) {
+        double a[17], b[17];
+#pragma unroll
+        for (int j = 0; j < 17; ++j) a[j] = ld_agent(&x[(size_t)j * stride + i]);
+#pragma unroll
+        for (int j = 0; j < 17; ++j) b[j] = ld_agent(&x[(size_t)j * stride + i + 64u]);
+#pragma unroll
+        for (int j = 0; j < 17; ++j) v[j] = (v[j] + a[j]) + b[j];
+    }
+    if (i < count) {
 #pragma unroll
         for (int j = 0; j < 17; ++j) v[j] += ld_agent(&x[(size_t)j * stride + i]);
     }
