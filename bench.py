@@ -63,6 +63,51 @@ def committed_traffic(kernel_prefix, points, k):
     return best
 
 
+def live_pmc(kernel_prefix, steps):
+    """HBM traffic and VALU instruction count of the step kernel measured NOW, on this box: three `rocprofv3 --pmc` passes
+    (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU -- one counter block per pass, as MI355X_MICROARCH.md prescribes) of this same
+    command in its short form, run as CHILD processes before this process touches the GPU.  Per-launch means over every
+    launch of the kernel in the child (pre-warm, warm-up, timed and instrumented iterations alike); bytes = FETCH_SIZE x 2
+    [gfx950: 128-byte requests counted as 64] x 1 KiB + WRITE_SIZE x 1 KiB, as tools/summarize_profile.py computes them for
+    the committed profile.  None when rocprofv3 is missing or a pass fails: the committed profile is quoted instead."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None
+    got, launches = {}, 0
+    base = "/tmp" if os.path.isdir("/tmp") else None
+    with tempfile.TemporaryDirectory(dir=base) as d:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+            od = os.path.join(d, ctr)
+            cmd = ["timeout", "-s", "KILL", "150", exe, "--pmc", ctr, "--output-format", "csv", "-d", od, "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", "3", "--prewarm-steps", "200",
+                   "--no-cpu-baseline", "--no-knn", "--no-extra", "--no-live-pmc"]
+            try:
+                r = subprocess.run(cmd, cwd=base, env=dict(os.environ, TMPDIR=base or ""), stdout=subprocess.DEVNULL,
+                                   stderr=subprocess.DEVNULL, timeout=200)
+            except (OSError, subprocess.SubprocessError):
+                return None
+            if r.returncode != 0:
+                return None
+            per = {}
+            for f in glob.glob(os.path.join(od, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        name = row["Kernel_Name"].replace("void ", "").replace("pcr::", "")
+                        if name.startswith(kernel_prefix) and row["Counter_Name"] == ctr:
+                            per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            if not per:
+                return None
+            got[ctr] = sum(per.values()) / len(per)
+            launches = len(per)
+    return {"traffic": got["FETCH_SIZE"] * 2048.0 + got["WRITE_SIZE"] * 1024.0, "read": got["FETCH_SIZE"] * 2048.0,
+            "written": got["WRITE_SIZE"] * 1024.0, "valu": got["SQ_INSTS_VALU"], "launches": launches}
+
+
 def cpu_baseline(src, tgt, R0, T0, k, sdft, ndft, budget_s=25.0):
     """The oracle (CPU restatement of the reference loop) timed on this box's host cores -- the CHECKER
     timed as a baseline, never the thing measured above.  Per iteration it does what the reference does:
@@ -233,12 +278,30 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-knn", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C5 (16 M LiDAR step) and C4 (batch of small fits) legs")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not collect the step kernel's counters with rocprofv3 child "
+                    "runs before the measurement (the committed profile is quoted instead, while it matches the sources)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher: be the launcher.  N fresh child processes, one per GPU, started
     # BEFORE anything here touches the GPU; rank 0's single JSON line is passed through.  (Never a silent one-GPU run.)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+
+    # The step kernel's counters, measured on THIS box by three short rocprofv3 child runs of this command -- before this
+    # process initialises the GPU (a profiled child must be started from a process that has not).  One GPU, headline
+    # workload only; anything going wrong leaves `live` None and the committed profile is quoted.
+    live = None
+    if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.no_live_pmc and args.points == 1_000_000 and args.k == 4
+            and not args.tune and os.environ.get("PCR_BENCH_EMULATE_SHARDS", "0") in ("", "0") and not os.environ.get("PCR_LIB")
+            and os.environ.get("PCR_BENCH_FORCE_DIST") != "1"
+            # (not when this process is itself being profiled: a profiler inside a profiler)
+            and "rocprof" not in os.environ.get("LD_PRELOAD", "").lower()
+            and not any(kk.startswith(("ROCPROF", "ROCP_")) for kk in os.environ)):
+        try:
+            live = live_pmc("icp_step_fast_kernel", args.steps)
+        except Exception as e:  # never let the counters cost the measurement
+            print(f"bench: live counter passes failed ({type(e).__name__}: {e})", file=sys.stderr)
+            live = None
 
     # Libraries underneath (RCCL prints a version banner) write to stdout; the contract is ONE JSON line there.
     # Everything but that line goes to stderr: fd 1 is pointed at fd 2 until the result is printed.
@@ -489,8 +552,15 @@ def main():
         algo_bytes = algorithmic_bytes_per_sample(k) * m
         achieved = algo_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
         info = tix.info()
-        traffic, traffic_src, valu_insts = (committed_traffic(capi.last_step_kernel(), n, k) if world == 1
-                                            else (None, "multi-GPU run", None))
+        if live is not None and capi.last_step_kernel().startswith("icp_step_fast_kernel"):
+            traffic, valu_insts = live["traffic"], live["valu"]
+            traffic_src = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU, one pass each, of "
+                           f"`bench.py --steps {args.steps} --warmup 3 --prewarm-steps 200 --no-knn --no-extra` as child processes "
+                           f"before the timed run; per-launch means over {live['launches']} launches; read {live['read']:.4g} B "
+                           f"(FETCH_SIZE x 2 KiB, gfx950 correction) + written {live['written']:.4g} B")
+        else:
+            traffic, traffic_src, valu_insts = (committed_traffic(capi.last_step_kernel(), n, k) if world == 1
+                                                else (None, "multi-GPU run", None))
         # VALU utilisation (north star): wave instructions x 4 issue cycles over the SIMD-cycles of the launch
         # (256 CUs x 4 SIMDs at the 2.4 GHz peak engine clock); instruction count from the committed PMC pass
         valu_util = (valu_insts * 4.0 / (1024 * step_ms * 1e-3 * 2.4e9)) if valu_insts and step_ms > 0 else None

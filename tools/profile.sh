@@ -18,7 +18,7 @@ cd "$R"
 # summariser runs later, in the container, possibly after the sources have moved on)
 python3 -c "from pointcloudregistration_amd.stamp import kernel_sources_stamp; print(kernel_sources_stamp())" > "$OUT/kernel_sources_stamp.txt"
 # second argument: the program to profile and its arguments (default: the bench)
-PROG=${2:-bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-knn --no-extra}
+PROG=${2:-bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-knn --no-extra --no-live-pmc}
 ARGS="$PROG"
 PARGS="$PROG"
 
