@@ -83,12 +83,12 @@ def live_pmc(kernel_prefix, steps):
     with tempfile.TemporaryDirectory(dir=base) as d:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
             od = os.path.join(d, ctr)
-            cmd = ["timeout", "-s", "KILL", "150", exe, "--pmc", ctr, "--output-format", "csv", "-d", od, "--",
+            cmd = ["timeout", "-s", "KILL", "60", exe, "--pmc", ctr, "--output-format", "csv", "-d", od, "--",
                    sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", "3", "--prewarm-steps", "200",
                    "--no-cpu-baseline", "--no-knn", "--no-extra", "--no-live-pmc"]
             try:
                 r = subprocess.run(cmd, cwd=base, env=dict(os.environ, TMPDIR=base or ""), stdout=subprocess.DEVNULL,
-                                   stderr=subprocess.DEVNULL, timeout=200)
+                                   stderr=subprocess.DEVNULL, timeout=90)
             except (OSError, subprocess.SubprocessError):
                 return None
             if r.returncode != 0:
