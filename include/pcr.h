@@ -336,7 +336,7 @@ int pcr_fit_enqueue_iterations(pcr_fit *fit, uint32_t count);
  * advances ALL of them by one iteration in a single kernel launch (each fit folds and solves for itself in the last
  * of its own blocks; a fit whose criteria have fired costs nothing in later launches).  The fits keep their own state:
  * pcr_fit_reset before, pcr_fit_read after, exactly as for a fit run alone -- and with bit-identical results.
- * Members must be on single-level grid indices with K <= 4 (K = 1 for all or for none); a member's sample set must not
+ * Members must be on single-level grid indices with K <= 8, every member's K in the same class (1, 2..4 or 5..8); a member's sample set must not
  * change while the batch exists.  The batch is destroyed before its members. */
 typedef struct pcr_fit_batch pcr_fit_batch;
 int pcr_fit_batch_create(pcr_ctx *ctx, pcr_fit *const *fits, uint32_t count, pcr_fit_batch **out);

@@ -27,6 +27,9 @@
 #ifndef PCR_FAST_WAVES
 #define PCR_FAST_WAVES 4
 #endif
+#ifndef PCR_FAST_WAVES8
+#define PCR_FAST_WAVES8 3  // K = 5..8: 168 registers hold the longer list without spills (1 M, K = 5: 236 -> 215 us; 2 waves: the same)
+#endif
 
 namespace pcr {
 
@@ -812,7 +815,7 @@ __device__ __forceinline__ void fast_tile(const StepArgs *__restrict__ Ap, uint3
 // with two / four such waves per block (which would keep neighbouring tiles on one CU's L1), and 135.7 for round 2's
 // four waves per block with a block-wide reduction and one ticket per block.
 template <int KC>
-__global__ void __launch_bounds__(64, PCR_FAST_WAVES) icp_step_fast_kernel(const StepArgs *__restrict__ Ap) {
+__global__ void __launch_bounds__(64, KC > 4 ? PCR_FAST_WAVES8 : PCR_FAST_WAVES) icp_step_fast_kernel(const StepArgs *__restrict__ Ap) {
     __shared__ __align__(16) unsigned char smem[WAVE_LDS_BYTES];
     const PCR_CONST_AS StepArgs *A = reload_from(Ap);
     if (reload_from(A->dyn)->done) return;  // uniform over the grid
@@ -824,7 +827,7 @@ __global__ void __launch_bounds__(64, PCR_FAST_WAVES) icp_step_fast_kernel(const
 // partials, folds and solves for itself in the wave that hands in its last tile, and drops out of later launches once
 // its criteria have fired.
 template <int KC>
-__global__ void __launch_bounds__(64, PCR_FAST_WAVES) icp_step_batch_kernel(const StepArgs *const *__restrict__ argv,
+__global__ void __launch_bounds__(64, KC > 4 ? PCR_FAST_WAVES8 : PCR_FAST_WAVES) icp_step_batch_kernel(const StepArgs *const *__restrict__ argv,
                                                                             const uint32_t *__restrict__ first,
                                                                             uint32_t count) {
     __shared__ __align__(16) unsigned char smem[WAVE_LDS_BYTES];
@@ -1172,17 +1175,19 @@ static thread_local const char *g_last_step_kernel = "none";
 static bool launch_step_kernels(pcr_ctx *ctx, const pcr_index *src, const StepArgs &A, uint32_t nt, uint32_t k,
                                 double *partials_d, const StepArgs *args_d) {
     const uint32_t nb = (nt + 3u) / 4u;
-    // single-level grids with fp32 shadows and K <= 4: the filtered kernel (tune 5: 1 = never, for A/B runs and tests)
-    const bool fast = src->kind == PCR_INDEX_GRID && g_tune[5] != 1 && k <= 4 && A.src.levels == 1 && A.tgt.levels == 1 &&
+    // single-level grids with key-space shadows and K <= 8: the filtered kernel (tune 5: 1 = never, for A/B runs and tests)
+    const bool fast = src->kind == PCR_INDEX_GRID && g_tune[5] != 1 && k <= 8 && A.src.levels == 1 && A.tgt.levels == 1 &&
                       A.src.v[0].shadow && A.tgt.v[0].shadow && args_d;
     if (fast) {
-        g_last_step_kernel = k == 1 ? "icp_step_fast_kernel<1>" : "icp_step_fast_kernel<4>";
+        g_last_step_kernel = k == 1 ? "icp_step_fast_kernel<1>" : k <= 4 ? "icp_step_fast_kernel<4>" : "icp_step_fast_kernel<8>";
         {
             ProfScope ps(ctx, PCR_PROF_STEP);
             if (k == 1)
                 hipLaunchKernelGGL(icp_step_fast_kernel<1>, dim3(nt), dim3(64), 0, ctx->stream, args_d);
-            else
+            else if (k <= 4)
                 hipLaunchKernelGGL(icp_step_fast_kernel<4>, dim3(nt), dim3(64), 0, ctx->stream, args_d);
+            else
+                hipLaunchKernelGGL(icp_step_fast_kernel<8>, dim3(nt), dim3(64), 0, ctx->stream, args_d);
         }
         if (A.tickets) return true;  // folded (and, with fit_inline in *args_d, solved) by the step kernel's last wave
         ProfScope ps(ctx, PCR_PROF_FOLD);
@@ -1777,18 +1782,20 @@ int pcr_fit_batch_create(pcr_ctx *ctx, pcr_fit *const *fits, uint32_t count, pcr
     *out = nullptr;
     std::vector<const StepArgs *> argv(count);
     std::vector<uint32_t> first(count + 1, 0);
-    const uint32_t kc = fits[0] ? (fits[0]->kc == 1 ? 1u : 4u) : 0u;
+    // the kernel instance a fit's K selects (the same three the single-fit launch picks from)
+    auto k_class = [](uint32_t k) { return k == 1 ? 1u : k <= 4 ? 4u : 8u; };
+    const uint32_t kc = fits[0] ? k_class(fits[0]->kc) : 0u;
     for (uint32_t i = 0; i < count; ++i) {
         const pcr_fit *f = fits[i];
         PCR_REQUIRE(f, "pcr_fit_batch_create: fits[%u] is NULL", i);
         PCR_REQUIRE(f->ctx == ctx, "pcr_fit_batch_create: fits[%u] was created on another context", i);
         for (uint32_t j = 0; j < i; ++j)
             PCR_REQUIRE(fits[j] != f, "pcr_fit_batch_create: fits[%u] and fits[%u] are the same fit", j, i);
-        const bool fast = f->src->kind == PCR_INDEX_GRID && f->kc <= 4 && f->args.src.levels == 1 && f->args.tgt.levels == 1 &&
+        const bool fast = f->src->kind == PCR_INDEX_GRID && f->kc <= 8 && f->args.src.levels == 1 && f->args.tgt.levels == 1 &&
                           f->args.src.v[0].shadow && f->args.tgt.v[0].shadow;
-        if (!fast || (f->kc == 1 ? 1u : 4u) != kc) {
-            set_last_error("pcr_fit_batch_create: fits[%u] cannot join this batch (needs single-level grid indices, K <= 4, "
-                           "and K = 1 either for all fits or for none)", i);
+        if (!fast || k_class(f->kc) != kc) {
+            set_last_error("pcr_fit_batch_create: fits[%u] cannot join this batch (needs single-level grid indices, K <= 8, "
+                           "and every fit's K in the same class: 1, 2..4 or 5..8)", i);
             return PCR_E_UNSUPPORTED;
         }
         argv[i] = f->args_d + 1;  // the copy whose step also solves
@@ -1819,13 +1826,16 @@ int pcr_fit_batch_create(pcr_ctx *ctx, pcr_fit *const *fits, uint32_t count, pcr
 int pcr_fit_batch_enqueue_iteration(pcr_fit_batch *b) {
     PCR_REQUIRE(b, "pcr_fit_batch_enqueue_iteration: NULL argument");
     PCR_HIP(hipSetDevice(b->ctx->device));
-    g_last_step_kernel = b->kc == 1 ? "icp_step_batch_kernel<1>" : "icp_step_batch_kernel<4>";
+    g_last_step_kernel = b->kc == 1 ? "icp_step_batch_kernel<1>" : b->kc == 4 ? "icp_step_batch_kernel<4>" : "icp_step_batch_kernel<8>";
     ProfScope ps(b->ctx, PCR_PROF_STEP);
     if (b->kc == 1)
         hipLaunchKernelGGL(icp_step_batch_kernel<1>, dim3(b->blocks), dim3(64), 0, b->ctx->stream, b->argv_d,
                            (const uint32_t *)b->first_d, b->count);
-    else
+    else if (b->kc == 4)
         hipLaunchKernelGGL(icp_step_batch_kernel<4>, dim3(b->blocks), dim3(64), 0, b->ctx->stream, b->argv_d,
+                           (const uint32_t *)b->first_d, b->count);
+    else
+        hipLaunchKernelGGL(icp_step_batch_kernel<8>, dim3(b->blocks), dim3(64), 0, b->ctx->stream, b->argv_d,
                            (const uint32_t *)b->first_d, b->count);
     PCR_HIP(hipGetLastError());
     return PCR_OK;

@@ -157,7 +157,7 @@ template <int KC>
 static void launch_knn(pcr_ctx *ctx, const pcr_index *ix, const double *q_d, const uint32_t *qorder, uint32_t nq,
                        uint32_t k, int order, double max_d2, uint32_t *oi_d, double *od_d) {
     const uint32_t nb = (nq + 255) / 256;
-    if constexpr (KC <= 4) {
+    if constexpr (KC <= 8) {
         if (ix->kind == PCR_INDEX_GRID && ix->view.levels == 1 && ix->view.v[0].shadow && ix->view_d && g_tune[5] != 1) {
             hipLaunchKernelGGL(knn_fast_kernel<KC>, dim3((nq + PCR_KNN_BLOCK - 1) / PCR_KNN_BLOCK), dim3(PCR_KNN_BLOCK), 0, ctx->stream,
                                (const MultiView *)ix->view_d, q_d, qorder, nq, (int)k, order, max_d2, oi_d, od_d);

@@ -103,7 +103,12 @@ def test_filtered_kernel_equals_the_fp64_walk_bit_for_bit(pcr, ctx):
                                  pcr.icp_step(ctx, six, tix, R, T, 4, U * 36.0, U * 4.0, exact=False),
                                  pcr.icp_step(ctx, six, tix, R, T, 1, U * 36.0, U * 4.0, exact=True),
                                  pcr.icp_step(ctx, six, tix, R, T, 2, U * 36.0, U * 4.0, sample_idx=smp, exact=True),
-                                 pcr.icp_step(ctx, six, tix, R, T, 3, U * 9.0, U * 1.0, sample_idx=smp, exact=False)]
+                                 pcr.icp_step(ctx, six, tix, R, T, 3, U * 9.0, U * 1.0, sample_idx=smp, exact=False),
+                                 pcr.icp_step(ctx, six, tix, R, T, 5, U * 36.0, U * 4.0, exact=True),
+                                 pcr.icp_step(ctx, six, tix, R, T, 6, U * 36.0, U * 4.0, sample_idx=smp, exact=False),
+                                 pcr.icp_step(ctx, six, tix, R, T, 7, U * 9.0, U * 1.0, sample_idx=smp, exact=True),
+                                 pcr.icp_step(ctx, six, tix, R, T, 8, U * 36.0, U * 4.0, exact=False)]
+                    assert pcr.last_step_kernel() == ("icp_step_grid_kernel" if mode else "icp_step_fast_kernel<8>")
             finally:
                 pcr.lib().pcr_tune(5, 0)
             for a, b in zip(out[1], out[0]):
@@ -129,6 +134,8 @@ def test_filtered_kernel_on_partial_scans_equals_the_fp64_walk(pcr, ctx):
             pcr.lib().pcr_tune(5, mode)
             out[mode] = [pcr.icp_step(ctx, six, tix, R, T, k, U * 36.0, U * 4.0, exact=ex) for k in (1, 2, 3, 4) for ex in (True, False)]
             assert pcr.last_step_kernel() == ("icp_step_grid_kernel" if mode else "icp_step_fast_kernel<4>")
+            out[mode] += [pcr.icp_step(ctx, six, tix, R, T, k, U * 36.0, U * 4.0, exact=ex) for k in (5, 8) for ex in (True, False)]
+            assert pcr.last_step_kernel() == ("icp_step_grid_kernel" if mode else "icp_step_fast_kernel<8>")
     finally:
         pcr.lib().pcr_tune(5, 0)
     unpaired = int((out[0][7]["fwd"] == 0xFFFFFFFF).sum())

@@ -87,7 +87,8 @@ def test_batched_concurrent_fits_equal_sequential(sequence, pcr):
         c.close()
 
 
-def test_one_launch_batch_equals_sequential(sequence, pcr):
+@pytest.mark.parametrize("k", [4, 6])
+def test_one_launch_batch_equals_sequential(sequence, pcr, k):
     """C4 as ONE launch per iteration (pcr_fit_batch): all pairs' fits on one context, advanced together by a single
     kernel whose blocks are split between the problems; every fit must reproduce its sequential run bit for bit --
     iteration count and state included (a fit that converges early idles in the remaining launches)."""
@@ -100,7 +101,7 @@ def test_one_launch_batch_equals_sequential(sequence, pcr):
     for s, t in pairs:
         six, tix = pcr.Index(ctx, pcr.Cloud(ctx, s)), pcr.Index(ctx, pcr.Cloud(ctx, t))
         U = tix.unique_sq_dist()
-        fits.append(pcr.Fit(ctx, six, tix, 4, U * 36.0, U * 4.0, conv=conv, unique_sq_dist=U, traj_cap=32))
+        fits.append(pcr.Fit(ctx, six, tix, k, U * 36.0, U * 4.0, conv=conv, unique_sq_dist=U, traj_cap=32))
     eye, zero = np.eye(3).reshape(9), np.zeros(3)
     ctx.synchronize()
     t0 = time.perf_counter()
@@ -115,11 +116,13 @@ def test_one_launch_batch_equals_sequential(sequence, pcr):
         batch.iterate()
     ctx.synchronize()
     t_bat = time.perf_counter() - t0
+    assert pcr.last_step_kernel() == ("icp_step_batch_kernel<4>" if k == 4 else "icp_step_batch_kernel<8>")
     for f, want in zip(fits, seq):
         got = f.read()
         assert got["iterations"] == want["iterations"] and got["state"] == want["state"]
         assert (got["traj"] == want["traj"]).all() and (got["R"] == want["R"]).all() and (got["T"] == want["T"]).all()
-    assert min(w["iterations"] for w in seq) < 30  # the case does contain fits that stop early
+    if k == 4:
+        assert min(w["iterations"] for w in seq) < 30  # the case does contain fits that stop early
     print(f"{len(fits)} fits: sequential {t_seq * 1e3:.2f} ms, one launch per iteration {t_bat * 1e3:.2f} ms")
     batch.close()
     ctx.close()
@@ -131,8 +134,10 @@ def test_batch_rejects_what_it_cannot_run(sequence, pcr):
     six, tix = pcr.Index(ctx, pcr.Cloud(ctx, scans[1])), pcr.Index(ctx, pcr.Cloud(ctx, scans[0]))
     k4 = pcr.Fit(ctx, six, tix, 4, 1e-4, 1e-4)
     k1 = pcr.Fit(ctx, six, tix, 1, 1e-4, 1e-4)
+    k6 = pcr.Fit(ctx, six, tix, 6, 1e-4, 1e-4)
+    k9 = pcr.Fit(ctx, six, tix, 9, 1e-4, 1e-4)
     foreign = pcr.Fit(other, six, tix, 4, 1e-4, 1e-4)
-    for members in ([k4, k1], [k4, foreign], [k4, k4]):  # mixed K classes; another context; the same fit twice
+    for members in ([k4, k1], [k4, k6], [k9], [k4, foreign], [k4, k4]):  # mixed K classes; K > 8; another context; the same fit twice
         with pytest.raises(pcr.PcrError):
             pcr.FitBatch(ctx, members)
     other.close()

@@ -34,7 +34,7 @@ def test_random_volume_vs_oracle(pcr, ctx, oracle, n, nq, k):
 
 
 def test_filtered_knn_equals_the_fp64_walk_bit_for_bit(pcr, ctx):
-    """pcr_knn through the fp32-filtered kernel (default on single-level grids, K <= 4) against the kernel in which every
+    """pcr_knn through the fp32-filtered kernel (default on single-level grids, K <= 8) against the kernel in which every
     candidate goes through the fp64 walk (pcr_tune key 5 = 1): indices AND squared distances, both orders, bounded and
     unbounded, queries on, near and far from the cloud."""
     from pointcloudregistration_amd import synth
@@ -43,7 +43,7 @@ def test_filtered_knn_equals_the_fp64_walk_bit_for_bit(pcr, ctx):
     U = tix.unique_sq_dist()
     rng = np.random.default_rng(4)
     q = np.concatenate([src @ Rm.T + t, tgt[:5000], tgt[:2000] + 3.0, rng.uniform(-2, 2, (3000, 3))])
-    for k in (1, 2, 3, 4):
+    for k in (1, 2, 3, 4, 5, 6, 7, 8):
         for order in (pcr.ORDER_ASCENDING, pcr.ORDER_DESCENDING):
             for max_d2 in (-1.0, 9.0 * U):
                 got = {}
