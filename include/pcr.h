@@ -64,7 +64,9 @@ const char *pcr_version(void);
  *   key 3: 1 = leave K-NN query batches in the caller's order
  *   key 4: (unused: the transformed copy of the source it chose is gone -- the reverse search always moves candidates as it reads them)
  *   key 5: 1 = neither the ICP step nor the K-NN entry points use the fp32-filtered kernels (every candidate goes
- *          through the fp64 walk) */
+ *          through the fp64 walk)
+ *   key 6: overrides pcr_index_params.compact_tables for indices built from now on: 0 = no override, 1 = dense tables
+ *          only, 2 = every level of a nested index compact, 3 = the levels under 1/8 occupancy compact */
 int pcr_tune(int key, int value);
 
 /* ---- context -----------------------------------------------------------------------
@@ -121,6 +123,11 @@ typedef struct {
     uint32_t brute_max_points;/* AUTO threshold; 0: 2048                                  */
     uint32_t max_levels;      /* nested grids for clouds of very uneven density (a dense
                                * region gets a finer grid of its own); 0: 6, 1: one grid  */
+    uint32_t compact_tables;  /* nested grids only.  0: every level keeps a start per cell
+                               * (fastest); 1: a level under 1/8 occupancy keeps occupancy
+                               * bits, ranks and a start per OCCUPIED cell instead (a 16 M
+                               * LiDAR sweep's index: 2.4 -> 0.9 GB, the iteration 8 % slower);
+                               * 2: every level does.  Results do not depend on it.        */
 } pcr_index_params;
 typedef struct {
     int kind;

@@ -36,7 +36,8 @@ class PcrError(RuntimeError):
 
 class IndexParams(C.Structure):
     _fields_ = [("kind", C.c_int), ("target_occupancy", C.c_double), ("cell_size", C.c_double),
-                ("max_cells", C.c_uint64), ("brute_max_points", C.c_uint32), ("max_levels", C.c_uint32)]
+                ("max_cells", C.c_uint64), ("brute_max_points", C.c_uint32), ("max_levels", C.c_uint32),
+                ("compact_tables", C.c_uint32)]
 
 
 class IndexInfo(C.Structure):
@@ -257,11 +258,11 @@ class Index:
     """pcr_index over a Cloud."""
 
     def __init__(self, ctx, cloud, kind=INDEX_AUTO, target_occupancy=0.0, cell_size=0.0, max_cells=0,
-                 brute_max_points=0, max_levels=0):
+                 brute_max_points=0, max_levels=0, compact_tables=0):
         self.ctx, self.cloud = ctx, cloud
         self.h = _vp()
         ctx._children.add(self)
-        prm = IndexParams(kind, target_occupancy, cell_size, max_cells, brute_max_points, max_levels)
+        prm = IndexParams(kind, target_occupancy, cell_size, max_cells, brute_max_points, max_levels, compact_tables)
         _check(lib().pcr_index_build(ctx.h, cloud.h, C.byref(prm), C.byref(self.h)), "pcr_index_build")
         self.n = cloud.n
 

@@ -31,6 +31,7 @@ constexpr uint32_t KEY_DIST_MASK = 0xFFFFF000u;  // 20 bits of distance; 12 bits
 __device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b) { return __builtin_elementwise_add_sat(a, b); }
 __device__ __forceinline__ uint32_t sat_sub(uint32_t a, uint32_t b) { return __builtin_elementwise_sub_sat(a, b); }
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // lanes 2i and 2i+1 swap a register (DPP quad_perm:[1,0,3,2]); every lane of the wave must be executing
 __device__ __forceinline__ uint32_t quad_swap1(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);
@@ -176,7 +177,9 @@ struct StageClock {
 // so that every field is a scalar load at its point of use).
 //   PAIR       the call is made by ALL 64 lanes of a wave together (`active`: this lane has a query): phase 3's gathers are
 //              then shared by lane pairs -- see there
-template <int KC, bool XF, bool SEEDED, int TRIES = 1, int U = PCR_FAST_U, int RS = PCR_ROW_STRIDE, bool PAIR = false, class GV, class RG>
+//   CT         the grid may carry a COMPACT cell table (GridView::cbits; levels of nested indices): phase 1 then reads
+//              each row's occupancy bits (two 8-byte loads) and four consecutive starts of occupied cells (one 16-byte load)
+template <int KC, bool XF, bool SEEDED, int TRIES = 1, int U = PCR_FAST_U, int RS = PCR_ROW_STRIDE, bool PAIR = false, bool CT = false, class GV, class RG>
 __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ exact_pts, double qx, double qy,
                                            double qz, double sx, double sy, double sz, double max_d2, double bound_d2,
                                            double bound_scale, double extra_margin, uint32_t delta, int k,
@@ -249,7 +252,6 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
         const int zstep = gx * gy;
         const bool has_xl = cx > 0, has_xh = cx < gx - 1;
         const bool y_lo = cy > 0, y_hi = cy < gy - 1, z_lo = cz > 0, z_hi = cz < gz - 1;
-        u32x4 b[9];
         uint32_t rowk_[9];
         bool open_[9];
 #pragma unroll
@@ -258,26 +260,79 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
             const bool inside = (DY[r] < 0 ? y_lo : (DY[r] > 0 ? y_hi : true)) & (DZ[r] < 0 ? z_lo : (DZ[r] > 0 ? z_hi : true));
             open_[r] = inside & !(rowk_[r] > UB0);
         }
-#ifdef PCR_FAST_SKIP_CLOSED_ROWS  // (measured: 127.4 against 127.7 us on the 1 M x 1 M step -- within the noise; left off)
-        // a row that is closed before it is read (outside the grid, or beyond what the caller's bound leaves open) asks for
-        // an offset past the end of the table: the buffer check answers zeros without a request to the cache
+        uint32_t P0[9], P1[9], P2[9], P3[9];  // the four boundaries of every row's three cells
+        bool compact = false;
+        if constexpr (CT) compact = g.cbits != nullptr;
+        if (compact) {
+            // cells a = c - has_xl .. c + has_xh of the row: their occupancy bits from the word(s) that hold them, the rank of
+            // cell a, then the starts of the rank-th occupied cell and the three behind it (cstart is padded for that) --
+            // cell a+i starts at q[number of occupied cells among a .. a+i-1].  A row outside the grid reads zeros or
+            // anything (the buffer check): it is masked, as below.
+            const uint32_t words = (cells >> 5) + 2u;
+            const __amdgpu_buffer_rsrc_t rs_cb = __builtin_amdgcn_make_buffer_rsrc((void *)g.cbits, 0, (int)(words * 8u), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_st = __builtin_amdgcn_make_buffer_rsrc((void *)g.cstart, 0, (int)0x7FFFFFFC, 0x00020000);
+            const uint32_t cb = cb4 >> 2;
+            u32x2 wa[9], wb[9];
+            uint32_t a_[9];
 #pragma unroll
-        for (int r = 0; r < 9; ++r)
-            b[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_cs, open_[r] ? cb4 + (uint32_t)(4 * (DY[r] * gx + DZ[r] * zstep)) : 0xFFFFFFF0u, 0, 0);
+            for (int r = 0; r < 9; ++r) {
+                const uint32_t c = cb + (uint32_t)(DY[r] * gx + DZ[r] * zstep);
+                a_[r] = c - (has_xl ? 1u : 0u);
+                wa[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_cb, (a_[r] >> 5) * 8u, 0, 0);
+                wb[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_cb, ((c + 1u) >> 5) * 8u, 0, 0);
+            }
+            u32x4 q[9];
+            uint32_t win_[9];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const uint32_t sh = a_[r] & 31u;
+                // (the second word matters only when the three cells straddle a word boundary: sh >= 30)
+                const unsigned long long bits = (unsigned long long)wa[r].x | ((unsigned long long)wb[r].x << 32);
+                uint32_t win = (uint32_t)(bits >> sh) & 7u;
+                win = has_xl ? win : (win << 1) & 7u;     // bit 0: cell c-1, bit 1: cell c, bit 2: cell c+1
+                win = has_xh ? win : win & 3u;
+                win_[r] = win;
+                const uint32_t rank = wa[r].y + (uint32_t)__popc(wa[r].x & ((1u << sh) - 1u));
+                q[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_st, open_[r] ? rank * 4u : 0u, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const uint32_t b0 = win_[r] & 1u, b01 = b0 + ((win_[r] >> 1) & 1u), b012 = b01 + (win_[r] >> 2);
+                P0[r] = q[r].x;
+                P1[r] = b0 ? q[r].y : q[r].x;
+                P2[r] = b01 == 0u ? q[r].x : (b01 == 1u ? q[r].y : q[r].z);
+                P3[r] = b012 == 0u ? q[r].x : (b012 == 1u ? q[r].y : (b012 == 2u ? q[r].z : q[r].w));
+            }
+        } else {
+            u32x4 b[9];
+#ifdef PCR_FAST_SKIP_CLOSED_ROWS  // (measured: 127.4 against 127.7 us on the 1 M x 1 M step -- within the noise; left off)
+            // a row that is closed before it is read (outside the grid, or beyond what the caller's bound leaves open) asks for
+            // an offset past the end of the table: the buffer check answers zeros without a request to the cache
+#pragma unroll
+            for (int r = 0; r < 9; ++r)
+                b[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_cs, open_[r] ? cb4 + (uint32_t)(4 * (DY[r] * gx + DZ[r] * zstep)) : 0xFFFFFFF0u, 0, 0);
 #else
 #pragma unroll
-        for (int r = 0; r < 9; ++r)
-            b[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_cs, cb4 + (uint32_t)(4 * (DY[r] * gx + DZ[r] * zstep)), 0, 0);
+            for (int r = 0; r < 9; ++r)
+                b[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_cs, cb4 + (uint32_t)(4 * (DY[r] * gx + DZ[r] * zstep)), 0, 0);
 #endif
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                // (the first element goes through an opaque copy: the compiler otherwise turns `has_xl ? b.x : b.y` into a
+                // run-time vector index and lowers THAT as a chain of three compare-and-selects over all four elements)
+                uint32_t bx = b[r].x;
+                asm volatile("" : "+v"(bx));
+                P0[r] = has_xl ? bx : b[r].y;
+                P1[r] = b[r].y;
+                P2[r] = b[r].z;
+                P3[r] = has_xh ? b[r].w : b[r].z;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
             const uint32_t rowk = rowk_[r];
             const bool open = open_[r];
-            // (the first element goes through an opaque copy: the compiler otherwise turns `has_xl ? b.x : b.y` into a
-            // run-time vector index and lowers THAT as a chain of three compare-and-selects over all four elements)
-            uint32_t bx = b[r].x;
-            asm volatile("" : "+v"(bx));
-            const uint32_t p0 = has_xl ? bx : b[r].y, p1 = b[r].y, p2 = b[r].z, p3 = has_xh ? b[r].w : b[r].z;
+            const uint32_t p0 = P0[r], p1 = P1[r], p2 = P2[r], p3 = P3[r];
             const uint32_t tot = p3 - p0;
             ok &= !(open & (tot > 255u));  // the payload holds 8 bits of offset: a longer row is the fp64 walk's business
             if (open & (tot != 0u)) {
@@ -555,7 +610,9 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
 // and (R,T) in DEVICE memory -- M and *xf may live in kernel arguments and registers, whose address cannot be handed
 // to the cooperative pass (not inlined) without the compiler copying all of it to every lane's scratch memory.
 // COOP = false: no pass 3 (pass 2 runs the shell search to its end in the lane; any subset of lanes may call).
-template <int KC, bool XF = false, bool COOP = true>
+// CT = false: the caller vouches that no level carries a compact cell table (GridView::cbits) -- the step kernel keeps an
+// instance without that path, which costs the 16 M LiDAR iteration 13.0 -> 14.0 ms when merely compiled in.
+template <int KC, bool XF = false, bool COOP = true, bool CT = true>
 __device__ __forceinline__ void multi_lane_search(const MultiView &M, const MultiView *M_mem, const Pt4 *__restrict__ cand_all, bool active, double qx,
                                                   double qy, double qz, double sx, double sy, double sz, double max_d2,
                                                   double bound_scale, double extra_margin, TopK<KC> &top, uint2 *rowtab,
@@ -612,7 +669,7 @@ __device__ __forceinline__ void multi_lane_search(const MultiView &M, const Mult
                                                          268435456.0);
                         double dk;
                         uint32_t ik;
-                        fast_ring1<KC, XF, false>(g, lvl_pts, qx, qy, qz, sx, sy, sz, reach, PCR_INF, bound_scale, extra_margin,
+                        fast_ring1<KC, XF, false, 1, PCR_FAST_U, PCR_ROW_STRIDE, false, CT>(g, lvl_pts, qx, qy, qz, sx, sy, sz, reach, PCR_INF, bound_scale, extra_margin,
                                                   delta, KC, 0.0, 0u, dk, ik, rowtab, xf, &fx);
                         if (fx.trusted && fx.cell[0] == cell_coord(sx, g.lo[0], g.inv_h, g.g[0]) &&
                             fx.cell[1] == cell_coord(sy, g.lo[1], g.inv_h, g.g[1]) &&
@@ -627,7 +684,7 @@ __device__ __forceinline__ void multi_lane_search(const MultiView &M, const Mult
                     }
                 }
                 if (!walked)
-                    settled = ring1_pruned<KC, XF>(g, lvl_pts, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top,
+                    settled = ring1_pruned<KC, XF, PCR_ROW_STRIDE, CT>(g, lvl_pts, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top,
                                                    rowtab, xf);
                 open |= settled ? 0u : 1u << l;
             }
@@ -644,7 +701,7 @@ __device__ __forceinline__ void multi_lane_search(const MultiView &M, const Mult
                      !ring1_settles(g, sx, sy, sz, g.margin + qmargin, bound_scale, top.worst_d(), max_d2);
             }
             if (go) {
-                const int r_done = grid_search<KC, true, XF, COOP ? PCR_LANE_RMAX : 0>(
+                const int r_done = grid_search<KC, true, XF, COOP ? PCR_LANE_RMAX : 0, CT>(
                     g, cand_all + (g.pts - M.all), qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, 2, xf);
                 left |= (uint32_t)r_done << (4 * l);  // (PCR_LANE_RMAX <= 15, at most 6 levels)
             }
@@ -675,7 +732,7 @@ __device__ __forceinline__ void multi_lane_search(const MultiView &M, const Mult
                 // other levels may have shrunk the K-th distance since this one was left open
                 const double b2 = level_box_dist2(g, usx, usy, usz, g.margin + uqm) * bound_scale;
                 if ((shared.worst_d() < b2) | (umax_d2 <= b2)) continue;
-                coop_shells<KC, XF>(&M_mem->v[l], cand_all + (g.pts - M.all), uqx, uqy, uqz, usx, usy, usz, umax_d2, bound_scale,
+                coop_shells<KC, XF, CT>(&M_mem->v[l], cand_all + (g.pts - M.all), uqx, uqy, uqz, usx, usy, usz, umax_d2, bound_scale,
                                     extra_margin, &shared, r_done, xf_mem);
             }
             if ((int)(threadIdx.x & 63u) == src) top = shared;

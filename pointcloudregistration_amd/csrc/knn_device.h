@@ -141,6 +141,30 @@ __device__ __forceinline__ int cell_coord(double v, double lo, double inv_h, int
     return (int)t;
 }
 
+// The positions [p, e) of the points of cells a .. b-1 (consecutive along x; b may be one past the last cell).
+// CT: the level may carry a compact cell table (GridView::cbits) -- only the searches of nested indices are compiled
+// with it; an empty range then costs no second load.
+__device__ __forceinline__ uint32_t cell_rank(const uint2 *__restrict__ cbits, size_t c) {
+    const uint2 w = cbits[c >> 5];
+    return w.y + (uint32_t)__popc(w.x & ((1u << (c & 31u)) - 1u));
+}
+template <bool CT, class GV>
+__device__ __forceinline__ void cell_range(const GV &g, size_t a, size_t b, uint32_t &p, uint32_t &e) {
+    if constexpr (CT) {
+        if (g.cbits) {
+            const uint32_t ra = cell_rank(g.cbits, a), rb = cell_rank(g.cbits, b);
+            p = e = 0;
+            if (ra != rb) {
+                p = g.cstart[ra];
+                e = g.cstart[rb];
+            }
+            return;
+        }
+    }
+    p = g.cs[a];
+    e = g.cs[b];
+}
+
 // Distance from coordinate s to the slab of cells with index c along one axis (0 inside), shrunk by the margin.
 __device__ __forceinline__ double slab_gap(double s, double lo, int c, double h, double margin) {
     const double f0 = lo + (double)c * h, f1 = lo + (double)(c + 1) * h;
@@ -258,12 +282,11 @@ __device__ __forceinline__ void windowed_scan(const Pt4 *__restrict__ order, con
 // top must be initialised by the caller (init(), or pre-seeded with a known candidate).
 // LANE_RMAX > 0: give up before a shell of a larger radius than that and return the radius of the cube scanned so far
 // (the caller continues from there -- coop_shells below).  Returns 0 when the search is finished.
-template <int KC, bool WINDOW = true, bool XF = false, int LANE_RMAX = 0>
+template <int KC, bool WINDOW = true, bool XF = false, int LANE_RMAX = 0, bool CT = false>
 __device__ __forceinline__ int grid_search(const GridView &g, const Pt4 *__restrict__ cand, double qx, double qy,
                                             double qz, double sx, double sy, double sz, double max_d2,
                                             double bound_scale, double extra_margin, TopK<KC> &top,
                                             int r_start = 1, const Rigid *xf = nullptr) {
-    const uint32_t *__restrict__ cs = g.cs;
     const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
     const int cx = cell_coord(sx, g.lo[0], g.inv_h, gx);
     const int cy = cell_coord(sy, g.lo[1], g.inv_h, gy);
@@ -428,8 +451,7 @@ __device__ __forceinline__ int grid_search(const GridView &g, const Pt4 *__restr
                                 DIAG_LANE_ADD(8 * (KC == 1) + 3, 1);  // rows opened by the shell search
                                 DG(diag_rows);
                                 const size_t base = ((size_t)rz * gy + ry) * gx;
-                                p = cs[base + xs];
-                                e = cs[base + xe + 1];
+                                cell_range<CT>(g, base + xs, base + xe + 1, p, e);
                                 if constexpr (WINDOW) {
                                     if (e - p > PCR_LONG_RANGE && e > p) {  // dense stretch: enter at the query's x instead
                                         windowed_scan<KC, XF>(g.pts, cand, p, e, qx, qy, qz, sx, margin, bound_scale, top, wd,
@@ -504,12 +526,11 @@ __device__ __forceinline__ int grid_search(const GridView &g, const Pt4 *__restr
 // RS: lanes per row of the table the caller handed in -- 256 in the 256-lane kernels, 64 in the filtered step kernel,
 // whose blocks are single waves.
 #define PCR_ROW_STRIDE 256
-template <int KC, bool XF = false, int RS = PCR_ROW_STRIDE>
+template <int KC, bool XF = false, int RS = PCR_ROW_STRIDE, bool CT = false>
 __device__ __forceinline__ bool ring1_pruned(const GridView &g, const Pt4 *__restrict__ cand, double qx, double qy,
                                              double qz, double sx, double sy, double sz, double max_d2,
                                              double bound_scale, double extra_margin, TopK<KC> &top, uint2 *rowtab,
                                              const Rigid *xf = nullptr) {
-    const uint32_t *__restrict__ cs = g.cs;
     const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
     const int cx = cell_coord(sx, g.lo[0], g.inv_h, gx);
     const int cy = cell_coord(sy, g.lo[1], g.inv_h, gy);
@@ -584,8 +605,7 @@ __device__ __forceinline__ bool ring1_pruned(const GridView &g, const Pt4 *__res
             if ((row.x != 0x7f800000u) & !(wd < gyz)) {
                 const uint32_t xs = (has_xl & !(wd < gyz + gxl)) ? row.y - 1u : row.y;
                 const uint32_t xe = (has_xh & !(wd < gyz + gxh)) ? row.y + 2u : row.y + 1u;
-                p = cs[xs];
-                e = cs[xe];
+                cell_range<CT>(g, xs, xe, p, e);
                 if (e - p > PCR_LONG_RANGE && e > p) {  // dense stretch: enter at the query's x instead
                     windowed_scan<KC, XF>(g.pts, cand, p, e, qx, qy, qz, sx, margin, bound_scale, top, wd, wi, xf);
                     p = e;
@@ -693,13 +713,12 @@ static_assert(PCR_LANE_RMAX >= 2 && PCR_LANE_RMAX <= 15, "packed four bits per l
 // after every shell the 64 lists are merged into the query's top-K (*shared, the same in every lane).  The shells, the
 // ball, the chords, the pruning and the stopping rule are grid_search's, so the result is the same exact K-NN.
 //   r_done: the cube of this radius around the query's cell has been scanned already.
-template <int KC, bool XF>
+template <int KC, bool XF, bool CT = false>
 __device__ PCR_COOP_INLINE void coop_shells(const GridView *gp, const Pt4 *__restrict__ cand, double qx, double qy, double qz,
                                             double sx, double sy, double sz, double max_d2, double bound_scale,
                                             double extra_margin, TopK<KC> *shared, int r_done, const Rigid *xf) {
     const int lane = (int)(threadIdx.x & 63u);
     const Pt4 *__restrict__ order = gp->pts;
-    const uint32_t *__restrict__ cs = gp->cs;
     const int gx = gp->g[0], gy = gp->g[1], gz = gp->g[2];
     const double h = gp->h, inv_h = gp->inv_h, lox = gp->lo[0], loy = gp->lo[1], loz = gp->lo[2];
     const int cx = cell_coord(sx, lox, inv_h, gx), cy = cell_coord(sy, loy, inv_h, gy), cz = cell_coord(sz, loz, inv_h, gz);
@@ -764,7 +783,8 @@ __device__ PCR_COOP_INLINE void coop_shells(const GridView *gp, const Pt4 *__res
                 xs = (int)lo_c;
                 xe = (int)hi_c;
                 if (xs > xe) continue;
-                const uint32_t p = cs[base + xs], e = cs[base + xe + 1];
+                uint32_t p, e;
+                cell_range<CT>(*gp, base + xs, base + xe + 1, p, e);
                 if (e - p > PCR_LONG_RANGE && e > p) {
                     windowed_scan<KC, XF>(order, cand, p, e, qx, qy, qz, sx, margin, bound_scale, mine, wd, wi, xf);
                 } else {

@@ -246,6 +246,39 @@ __global__ void __launch_bounds__(256) pack_kernel(const double *__restrict__ xy
 }
 
 // ------------------------------------------------------------------ strip table
+// ---- compact cell table (GridView::cbits / cstart) from the dense one.  One thread per cell; a wave's ballot is the
+// occupancy word of 64 cells, i.e. of two table words.
+__global__ void __launch_bounds__(256) cell_bits_kernel(const uint32_t *__restrict__ cs, uint64_t cells, uint64_t words,
+                                                        uint2 *__restrict__ cbits, uint32_t *__restrict__ word_pop) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const int lane = (int)(threadIdx.x & 63u);
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < words * 32u; c += stride) {
+        const bool occ = c < cells && cs[c + 1] > cs[c];
+        const unsigned long long m = __ballot(occ);
+        if ((lane & 31) == 0) {
+            const uint32_t bits = (uint32_t)(m >> lane);
+            cbits[c >> 5].x = bits;
+            word_pop[c >> 5] = (uint32_t)__popc(bits);
+        }
+    }
+}
+
+// word_rank: the exclusive scan of word_pop.  Writes the ranks into the table's words and every occupied cell's start
+// to its place in cstart; cstart[occupied .. occupied+3] = n.
+__global__ void __launch_bounds__(256) cell_compact_kernel(const uint32_t *__restrict__ cs, uint64_t cells, uint64_t words,
+                                                           const uint32_t *__restrict__ word_rank, uint2 *__restrict__ cbits,
+                                                           uint32_t *__restrict__ cstart, uint32_t occupied, uint32_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t first = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (first < 4) cstart[occupied + first] = n;
+    for (uint64_t c = first; c < words * 32u; c += stride) {
+        const uint64_t w = c >> 5;
+        const uint32_t bits = cbits[w].x, rank = word_rank[w], b = (uint32_t)(c & 31u);
+        if (b == 0) cbits[w].y = rank;
+        if (c < cells && ((bits >> b) & 1u)) cstart[rank + (uint32_t)__popc(bits & ((1u << b) - 1u))] = cs[c];
+    }
+}
+
 // Points per strip cell: a strip is 8x8 (y,z) rows of cells, x stays at full resolution (GridView::cs8).  One thread
 // per strip cell; consecutive threads are consecutive x, so every one of the 64 reads is coalesced.
 __global__ void __launch_bounds__(256) strip_count_kernel(const uint32_t *__restrict__ cs, int gx, int gy, int gz, int gy8,
@@ -985,6 +1018,8 @@ int pcr_index_free(pcr_index *ix) {
     for (int l = 0; l < PCR_MAX_LEVELS; ++l) {
         if (ix->cs_raw_d[l]) hipFree(ix->cs_raw_d[l]);
         if (ix->cs8_d[l]) hipFree(ix->cs8_d[l]);
+        if (ix->cbits_d[l]) hipFree(ix->cbits_d[l]);
+        if (ix->cstart_d[l]) hipFree(ix->cstart_d[l]);
     }
     if (ix->pos_of_d) hipFree(ix->pos_of_d);
     if (ix->order_d) hipFree(ix->order_d);
@@ -1240,6 +1275,8 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
             V.pts = ix->pts_d;
             V.cs = nullptr;
             V.cs8 = nullptr;
+            V.cbits = nullptr;
+            V.cstart = nullptr;
             V.gy8 = 1;
             V.h = V.inv_h = 1.0;
             V.g[0] = V.g[1] = V.g[2] = 1;
@@ -1272,7 +1309,7 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
             hi[a] = cloud->hi[a];
         }
         uint32_t n_l = n, off = 0;
-        uint64_t occupied_total = 0, cells_total = 0;
+        uint64_t occupied_total = 0, cells_total = 0, table_bytes = 0;
         uint32_t max_occ = 0;
         for (int l = 0;; ++l) {
             const uint8_t *filter = lvl_d;  // NULL while nothing has been split off: every point is level 0
@@ -1360,13 +1397,55 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
             V.n = n_l;
             V.pts = ix->pts_d + off;
             V.cs = B.counts_d;
+            V.cbits = nullptr;
+            V.cstart = nullptr;
             V.h = B.h;
             V.inv_h = B.G.inv_h;
-            ix->cs_d[l] = B.counts_d;  // the index owns the table from here on
-            ix->cs_raw_d[l] = B.counts_raw;
             ix->cells[l] = B.cells;
-            B.counts_raw = B.counts_d = nullptr;
-            B.counts_cap = 0;
+            ix->occupied[l] = B.stats_h[0];
+            // ---- on request (pcr_index_params.compact_tables, tune 6) a level of a nested index trades its dense table
+            // for the compact one (GridView::cbits)
+            const bool nested = l > 0 || n_inner > 0;
+            const int compact_mode = g_tune[6] == 1 ? 0 : g_tune[6] == 2 ? 2 : g_tune[6] == 3 ? 1 : (int)P.compact_tables;
+            if (nested && (compact_mode >= 2 || (compact_mode == 1 && B.cells >= (1u << 16) && B.stats_h[0] * 8 < B.cells))) {
+                const uint64_t words = B.cells / 32 + 2;
+                const uint32_t occupied = (uint32_t)B.stats_h[0];
+                const uint32_t wtiles = (uint32_t)((words + SCAN_TILE - 1) / SCAN_TILE);
+                uint32_t *word_rank_d = nullptr, *wtiles_d = nullptr;
+                BUILD_HIP(hipMalloc(&ix->cbits_d[l], sizeof(uint2) * words));
+                BUILD_HIP(hipMalloc(&ix->cstart_d[l], sizeof(uint32_t) * ((size_t)occupied + 4)));
+                hipError_t ec = hipMalloc(&word_rank_d, sizeof(uint32_t) * (words + 1));
+                if (ec == hipSuccess) ec = hipMalloc(&wtiles_d, sizeof(uint32_t) * (wtiles + 1));
+                if (ec == hipSuccess) {
+                    hipLaunchKernelGGL(cell_bits_kernel, dim3(grid_blocks(words * 32, 256, 16384)), dim3(256), 0, ctx->stream,
+                                       (const uint32_t *)B.counts_d, B.cells, words, ix->cbits_d[l], word_rank_d);
+                    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(wtiles), dim3(256), 0, ctx->stream, (const uint32_t *)word_rank_d,
+                                       words, wtiles_d, stats_d);
+                    hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, wtiles_d, wtiles);
+                    hipLaunchKernelGGL(scan_apply_kernel, dim3(wtiles), dim3(256), 0, ctx->stream, word_rank_d, words,
+                                       (const uint32_t *)wtiles_d, occupied);
+                    hipLaunchKernelGGL(cell_compact_kernel, dim3(grid_blocks(words * 32, 256, 16384)), dim3(256), 0, ctx->stream,
+                                       (const uint32_t *)B.counts_d, B.cells, words, (const uint32_t *)word_rank_d, ix->cbits_d[l],
+                                       ix->cstart_d[l], occupied, n_l);
+                    ec = hipStreamSynchronize(ctx->stream);
+                }
+                if (word_rank_d) hipFree(word_rank_d);
+                if (wtiles_d) hipFree(wtiles_d);
+                BUILD_HIP(ec);
+                BUILD_HIP(hipGetLastError());
+                V.cs = nullptr;
+                V.cbits = ix->cbits_d[l];
+                V.cstart = ix->cstart_d[l];
+                table_bytes += sizeof(uint2) * words + sizeof(uint32_t) * ((uint64_t)occupied + 4);
+                // (the dense table stays with B: the next level's histogram reuses the allocation if it fits)
+            } else {
+                ix->cs_d[l] = B.counts_d;  // the index owns the table from here on
+                ix->cs_raw_d[l] = B.counts_raw;
+                B.counts_raw = B.counts_d = nullptr;
+                B.counts_cap = 0;
+                table_bytes += sizeof(uint32_t) * (B.cells + 3);
+            }
+            table_bytes += sizeof(uint32_t) * (strips + 1);
             M.levels = l + 1;
             if (getenv("PCR_TRACE_BUILD"))
                 fprintf(stderr, "[pcr] level %d: n=%u h=%.6g dims=%dx%dx%d cells=%llu occupied=%llu largest=%llu box=[%.3g %.3g %.3g]-[%.3g %.3g %.3g]\n",
@@ -1431,7 +1510,7 @@ int pcr_index_build(pcr_ctx *ctx, const pcr_cloud *cloud, const pcr_index_params
         ix->info.mean_occupancy = (double)n / (double)(occupied_total ? occupied_total : 1);
         ix->info.max_occupancy = max_occ;
         ix->info.levels = (uint32_t)M.levels;
-        ix->info.device_bytes = (sizeof(Pt4) + 8 + (ix->shadow_d ? 8 : 0)) * (uint64_t)n + 4 * (cells_total + M.levels) + cells_total / 8;
+        ix->info.device_bytes = (sizeof(Pt4) + 8 + (ix->shadow_d ? 8 : 0)) * (uint64_t)n + table_bytes;
     }
     release(B);
     if (stats_d) hipFree(stats_d);

@@ -369,7 +369,7 @@ __device__ uint32_t g_fast_clocks[16 * 65536];          // ... and wave 0's shad
 #else
 #define FAST_STAMP(i) do { } while (0)
 #endif
-template <int KC, bool MULTI>
+template <int KC, int MULTI>  // 0: single-level; 1: nested, dense cell tables only; 2: nested, some level has a compact table
 __global__ void __launch_bounds__(256, MULTI ? PCR_MULTI_WAVES : PCR_STEP_WAVES) icp_step_grid_kernel(StepArgs A) {
     const StepDyn *__restrict__ dynp = A.dyn;
     if (dynp->done) return;  // uniform over the grid
@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(256, MULTI ? PCR_MULTI_WAVES : PCR_STEP_WAVES)
     static_assert(sizeof(uint2) * 9 * 256 <= REDUCE17_LDS_BYTES, "row table fits");
     uint2 *my_rows = (uint2 *)smem + threadIdx.x;
     if constexpr (MULTI) {  // (every lane calls: the level search finishes its longest queries wave-cooperatively)
-        multi_lane_search<KC>(A.tgt, A.tgt_mem, A.tgt.all, fin, px, py, pz, px, py, pz, fmax_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
+        multi_lane_search<KC, false, true, MULTI == 2>(A.tgt, A.tgt_mem, A.tgt.all, fin, px, py, pz, px, py, pz, fmax_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
                               my_rows);
     } else if (fin) {
         lane_search<KC>(A.tgt.v[0], A.tgt.all, px, py, pz, px, py, pz, fmax_d2, 1.0 - 1.8189894035458565e-12, 0.0, top,
@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(256, MULTI ? PCR_MULTI_WAVES : PCR_STEP_WAVES)
     rt.idx[0] = orig;
     const bool rev_active = need_rev && isfinite(sx) && isfinite(sy) && isfinite(sz);
     if constexpr (MULTI) {
-        multi_lane_search<1, true>(A.src, A.src_mem, A.src.all, rev_active, qx, qy, qz, sx, sy, sz, PCR_INF, D.rev_bound_scale,
+        multi_lane_search<1, true, true, MULTI == 2>(A.src, A.src_mem, A.src.all, rev_active, qx, qy, qz, sx, sy, sz, PCR_INF, D.rev_bound_scale,
                                    D.rev_extra_margin, rt, my_rows, &D.M, &dynp->M);
     } else if (rev_active) {
         lane_search<1, true>(A.src.v[0], A.src.all, qx, qy, qz, sx, sy, sz, PCR_INF, D.rev_bound_scale, D.rev_extra_margin,
@@ -1195,15 +1195,20 @@ static bool launch_step_kernels(pcr_ctx *ctx, const pcr_index *src, const StepAr
                            partials_d);
         return false;
     }
+    bool compact = false;  // some level of either index carries a compact cell table
+    for (int l = 0; l < A.src.levels; ++l) compact |= A.src.v[l].cbits != nullptr;
+    for (int l = 0; l < A.tgt.levels; ++l) compact |= A.tgt.v[l].cbits != nullptr;
     g_last_step_kernel = src->kind != PCR_INDEX_GRID ? "icp_step_brute_kernel"
-                         : (A.src.levels > 1 || A.tgt.levels > 1) ? "icp_step_grid_kernel<multi-level>"
+                         : (A.src.levels > 1 || A.tgt.levels > 1) ? (compact ? "icp_step_grid_kernel<multi-level, compact tables>" : "icp_step_grid_kernel<multi-level>")
                                                                   : "icp_step_grid_kernel";
 #define LAUNCH_STEP(KC)                                                                               \
     do {                                                                                              \
-        if (src->kind == PCR_INDEX_GRID && (A.src.levels > 1 || A.tgt.levels > 1))                    \
-            hipLaunchKernelGGL((icp_step_grid_kernel<KC, true>), dim3(nb), dim3(256), 0, ctx->stream, A);  \
+        if (src->kind == PCR_INDEX_GRID && (A.src.levels > 1 || A.tgt.levels > 1) && compact)         \
+            hipLaunchKernelGGL((icp_step_grid_kernel<KC, 2>), dim3(nb), dim3(256), 0, ctx->stream, A);  \
+        else if (src->kind == PCR_INDEX_GRID && (A.src.levels > 1 || A.tgt.levels > 1))               \
+            hipLaunchKernelGGL((icp_step_grid_kernel<KC, 1>), dim3(nb), dim3(256), 0, ctx->stream, A);  \
         else if (src->kind == PCR_INDEX_GRID)                                                         \
-            hipLaunchKernelGGL((icp_step_grid_kernel<KC, false>), dim3(nb), dim3(256), 0, ctx->stream, A); \
+            hipLaunchKernelGGL((icp_step_grid_kernel<KC, 0>), dim3(nb), dim3(256), 0, ctx->stream, A); \
         else                                                                                          \
             hipLaunchKernelGGL(icp_step_brute_kernel<KC>, dim3(nb), dim3(256), 0, ctx->stream, A);    \
     } while (0)

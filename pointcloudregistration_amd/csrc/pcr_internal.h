@@ -42,7 +42,14 @@ struct __attribute__((aligned(32))) Pt4 {
 // What the query kernels need to know about an index (passed by value).
 struct GridView {
     const Pt4 *pts;       // [n] in cell order (GRID) or in original order (BRUTE)
-    const uint32_t *cs;   // [cells+1] exclusive cell starts; NULL for BRUTE
+    const uint32_t *cs;   // [cells+1] exclusive cell starts; NULL for BRUTE and for a level with a COMPACT table:
+    // ---- compact cell table (sparse levels of nested indices: a LiDAR sweep's fine levels occupy under 1 % of their
+    // cells, and a dense table is gigabytes of zeros' worth of repeated starts).  cbits[w] = {occupancy bits of cells
+    // 32w .. 32w+31, number of occupied cells before cell 32w}; cstart[j] = start of the j-th occupied cell, [occupied] = n
+    // (three more copies of n behind it).  The dense table's entry c is cstart[rank(c)], rank(c) = the occupied cells
+    // before c: one 8-byte load, a popcount, one dependent 4-byte load; an empty range is known after the first.
+    const uint2 *cbits;       // [cells / 32 + 2]; NULL: the level has the dense table
+    const uint32_t *cstart;   // [occupied + 4]
     const uint32_t *cs8;  // [g[0]*gy8*gz8 + 1] the same for STRIPS of 8x8 (y,z) rows, x at full resolution: the
                           // points of cells x0..x1 of a strip number cs8[b+x1+1] - cs8[b+x0] -- zero lets a search
                           // skip 64 rows with two loads.  NULL for BRUTE
@@ -186,5 +193,8 @@ struct pcr_index {
     uint32_t *cs_raw_d[pcr::PCR_MAX_LEVELS];  // the allocations behind cs_d: cs_d - 1, [cells+3] (a zero entry either side)
     uint64_t cells[pcr::PCR_MAX_LEVELS];
     uint32_t *cs8_d[pcr::PCR_MAX_LEVELS];   // strip tables (GridView::cs8)
+    uint2 *cbits_d[pcr::PCR_MAX_LEVELS];    // compact tables (GridView::cbits, cstart); cs_d[l] is NULL where a level has one
+    uint32_t *cstart_d[pcr::PCR_MAX_LEVELS];
+    uint64_t occupied[pcr::PCR_MAX_LEVELS];  // occupied cells of every level
     pcr_index_info info;
 };

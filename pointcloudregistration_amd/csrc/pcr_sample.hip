@@ -47,6 +47,14 @@ struct CellPick {
     __device__ uint32_t value(uint64_t c) const { return (uint32_t)pts[cs[c]].w; }
 };
 
+// the same over a level's COMPACT cell table (GridView::cstart): every entry is an occupied cell, in cell order
+struct OccupiedPick {
+    const uint32_t *cstart;
+    const Pt4 *pts;
+    __device__ bool keep(uint64_t) const { return true; }
+    __device__ uint32_t value(uint64_t j) const { return (uint32_t)pts[cstart[j]].w; }
+};
+
 constexpr int PICK_TILE = 1024;  // items per block (4 per thread)
 
 template <typename P>
@@ -169,8 +177,11 @@ int pcr_sample_grid(pcr_ctx *ctx, const pcr_index *index, uint32_t cap, uint32_t
     uint32_t total = 0;
     for (int l = 0; l < index->view.levels; ++l) {
         uint32_t got = 0;
-        int rc = pick_compact(ctx, CellPick{index->cs_d[l], index->view.v[l].pts}, index->cells[l], cap - total, out_idx + total,
-                              &got, false);
+        int rc = index->cstart_d[l]
+                     ? pick_compact(ctx, OccupiedPick{index->cstart_d[l], index->view.v[l].pts}, index->occupied[l], cap - total,
+                                    out_idx + total, &got, false)
+                     : pick_compact(ctx, CellPick{index->cs_d[l], index->view.v[l].pts}, index->cells[l], cap - total, out_idx + total,
+                                    &got, false);
         if (rc != PCR_OK) return rc;
         total += got;
     }

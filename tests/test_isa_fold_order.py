@@ -106,7 +106,7 @@ def test_every_ticket_is_drawn_after_the_partial_sums_were_acknowledged(tmp_path
         with_tickets += 1
     # the two filtered instances (the headline path), the batch kernel, the fp64 walk, brute force, the normal-aware one
     for must in ("icp_step_fast_kernelILi4E", "icp_step_fast_kernelILi1E", "icp_step_batch_kernelILi4E",
-                 "icp_step_grid_kernelILi4ELb0E", "icp_step_grid_kernelILi4ELb1E", "icp_step_brute_kernelILi4E"):
+                 "icp_step_grid_kernelILi4ELi0E", "icp_step_grid_kernelILi4ELi1E", "icp_step_grid_kernelILi4ELi2E", "icp_step_brute_kernelILi4E"):
         assert any(must in n for n in step), f"{must} not found among {sorted(step)}"
     assert with_tickets == len(step)
 

@@ -21,14 +21,20 @@ def main():
     ap.add_argument("--k", type=int, default=4)
     ap.add_argument("--occupancy", type=float, default=0.0, help="index target occupancy (0: library default)")
     ap.add_argument("--max-cells", type=int, default=0, help="cap on a level's cell table (0: library default)")
+    ap.add_argument("--tables", type=int, default=0, help="pcr_index_params.compact_tables: 0 = dense cell tables (default), "
+                    "1 = compact tables for the levels under 1/8 occupancy, 2 = for every level")
     ap.add_argument("--fit", type=int, default=0, help="instead: a device-resident fit of this many iterations from a "
                     "perturbed start; prints every iteration's kernel time (what the temporal bounds buy shows from the second)")
     a = ap.parse_args()
     from pointcloudregistration_amd import capi as pcr, synth
     src, tgt, Rm, t = synth.lidar_pair(a.n, 516, outlier_frac=a.outliers)
     ctx = pcr.Context(0)
-    six = pcr.Index(ctx, pcr.Cloud(ctx, src), target_occupancy=a.occupancy, max_cells=a.max_cells)
-    tix = pcr.Index(ctx, pcr.Cloud(ctx, tgt), target_occupancy=a.occupancy, max_cells=a.max_cells)
+    import time
+    t_build = time.perf_counter()
+    six = pcr.Index(ctx, pcr.Cloud(ctx, src), target_occupancy=a.occupancy, max_cells=a.max_cells, compact_tables=a.tables)
+    tix = pcr.Index(ctx, pcr.Cloud(ctx, tgt), target_occupancy=a.occupancy, max_cells=a.max_cells, compact_tables=a.tables)
+    ctx.synchronize()
+    t_build = time.perf_counter() - t_build
     U = tix.unique_sq_dist()
     R, T = synth.colmajor(Rm), t
     if a.fit > 0:
@@ -54,7 +60,7 @@ def main():
     si, ti = six.info(), tix.info()
     print(json.dumps({"workload": f"C5 lidar {a.n}x{a.n}, {a.outliers:.0%} outliers, K={a.k}", "step_ms": ms / max(cnt, 1),
                       "launches": cnt, "samples_per_s": a.n / (ms / max(cnt, 1) * 1e-3), "kept_pairs": float(out["partials"][0]),
-                      "kernel": pcr.last_step_kernel(),
+                      "kernel": pcr.last_step_kernel(), "tables": a.tables, "build_s_both": round(t_build, 3),
                       "src_index": {k: si[k] for k in ("levels", "cells", "occupied_cells", "device_bytes")},
                       "tgt_index": {k: ti[k] for k in ("levels", "cells", "occupied_cells", "device_bytes")}}))
 
