@@ -620,6 +620,7 @@ __device__ __forceinline__ void multi_lane_search(const MultiView &M, const Mult
     const int L = M.levels;
     const double qmargin = extra_margin + 9.094947017729282e-13 * (fabs(sx) + fabs(sy) + fabs(sz));
     uint32_t holds = 0, open = 0;
+    const unsigned long long diag_p0 = DIAG_T();  // (diagnostic build: the wave's time in each of the three passes, slots 42..47)
     if (active)
         for (int it = 0; it < 2 * L; ++it) {
             const int l = it < L ? L - 1 - it : it - L;
@@ -689,7 +690,9 @@ __device__ __forceinline__ void multi_lane_search(const MultiView &M, const Mult
                 open |= settled ? 0u : 1u << l;
             }
         }
+    DIAG_ADD(42 + 3 * XF, DIAG_T() - diag_p0);
     if (__any(open != 0)) {
+        const unsigned long long diag_p1 = DIAG_T();
         uint32_t left = 0;
         for (int it = 0; it < 2 * L; ++it) {
             const int l = it < L ? L - 1 - it : it - L;
@@ -701,11 +704,26 @@ __device__ __forceinline__ void multi_lane_search(const MultiView &M, const Mult
                      !ring1_settles(g, sx, sy, sz, g.margin + qmargin, bound_scale, top.worst_d(), max_d2);
             }
             if (go) {
-                const int r_done = grid_search<KC, true, XF, COOP ? PCR_LANE_RMAX : 0, CT>(
-                    g, cand_all + (g.pts - M.all), qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, 2, xf);
+                // the 5x5x5 cells first, a layer's rows looked up together; what that leaves open goes on shell by shell
+                int r_done = 0;
+                if (!shell2_batched<KC, XF, PCR_ROW_STRIDE, CT>(g, cand_all + (g.pts - M.all), qx, qy, qz, sx, sy, sz, max_d2, bound_scale,
+                                                                extra_margin, top, rowtab, xf)) {
+                    // the next radius by grid_search's rule: double, but never past what the ball of everything that can
+                    // still matter needs
+                    int r_first = 4;
+                    const double reach2 = fmin(top.worst_d(), max_d2);
+                    if (reach2 < PCR_INF) {
+                        const double cells_needed = (sqrt(reach2 / bound_scale) + g.margin + qmargin) * g.inv_h + 2.0;
+                        r_first = cells_needed < 4.0 ? max((int)cells_needed, 3) : 4;
+                    }
+                    r_done = grid_search<KC, true, XF, COOP ? PCR_LANE_RMAX : 0, CT>(
+                        g, cand_all + (g.pts - M.all), qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, 3, xf, r_first);
+                }
                 left |= (uint32_t)r_done << (4 * l);  // (PCR_LANE_RMAX <= 15, at most 6 levels)
             }
         }
+        DIAG_ADD(43 + 3 * XF, DIAG_T() - diag_p1);
+        const unsigned long long diag_p2 = DIAG_T();
         // ---- pass 3: one unfinished query at a time, by the whole wave ----
         unsigned long long pending = COOP ? __ballot(left != 0) : 0ull;
         while (pending) {
@@ -737,6 +755,7 @@ __device__ __forceinline__ void multi_lane_search(const MultiView &M, const Mult
             }
             if ((int)(threadIdx.x & 63u) == src) top = shared;
         }
+        DIAG_ADD(44 + 3 * XF, DIAG_T() - diag_p2);
     }
 }
 

@@ -19,9 +19,16 @@ namespace pcr {
 // diagnostic build only (libpcr_diag.so): counters of the lane search.  Never compiled into libpcr.so.
 static __device__ unsigned long long g_diag[48];  // (32..47: the filtered step kernel's own, pcr_icp.hip)
 #define DIAG_T() ((unsigned long long)__builtin_amdgcn_s_memtime())
+// PCR_DIAG_LIGHT: only the per-wave TIME slots (42..47) are kept -- a handful of atomics per wave, where the event counters'
+// per-lane atomics slow a kernel tenfold and distort every share
+#ifdef PCR_DIAG_LIGHT
+#define DIAG_KEEP(slot) ((slot) >= 42)
+#else
+#define DIAG_KEEP(slot) true
+#endif
 #define DIAG_ADD(slot, v)                                                                \
     do {                                                                                 \
-        if ((int)(threadIdx.x & 63) == __ffsll((unsigned long long)__ballot(1)) - 1) atomicAdd(&g_diag[slot], (unsigned long long)(v)); \
+        if (DIAG_KEEP(slot) && (int)(threadIdx.x & 63) == __ffsll((unsigned long long)__ballot(1)) - 1) atomicAdd(&g_diag[slot], (unsigned long long)(v)); \
     } while (0)
 #else
 #define DIAG_T() 0ull
@@ -29,7 +36,7 @@ static __device__ unsigned long long g_diag[48];  // (32..47: the filtered step 
     do {                  \
     } while (0)
 #endif
-#ifdef PCR_DIAG
+#if defined(PCR_DIAG) && !defined(PCR_DIAG_LIGHT)
 #define DIAG_LANE_ADD(slot, v) atomicAdd(&g_diag[slot], (unsigned long long)(v))
 #else
 #define DIAG_LANE_ADD(slot, v) \
@@ -280,13 +287,14 @@ __device__ __forceinline__ void windowed_scan(const Pt4 *__restrict__ order, con
 //   max_d2   : candidates with d2 >= max_d2 are of no interest; the search may stop as soon as every
 //              unvisited point is at least that far
 // top must be initialised by the caller (init(), or pre-seeded with a known candidate).
+// r_first (0: r_start): the radius of the first shell, when the caller knows that a wider one is needed anyway.
 // LANE_RMAX > 0: give up before a shell of a larger radius than that and return the radius of the cube scanned so far
 // (the caller continues from there -- coop_shells below).  Returns 0 when the search is finished.
 template <int KC, bool WINDOW = true, bool XF = false, int LANE_RMAX = 0, bool CT = false>
 __device__ __forceinline__ int grid_search(const GridView &g, const Pt4 *__restrict__ cand, double qx, double qy,
                                             double qz, double sx, double sy, double sz, double max_d2,
                                             double bound_scale, double extra_margin, TopK<KC> &top,
-                                            int r_start = 1, const Rigid *xf = nullptr) {
+                                            int r_start = 1, const Rigid *xf = nullptr, int r_first = 0) {
     const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
     const int cx = cell_coord(sx, g.lo[0], g.inv_h, gx);
     const int cy = cell_coord(sy, g.lo[1], g.inv_h, gy);
@@ -328,7 +336,9 @@ __device__ __forceinline__ int grid_search(const GridView &g, const Pt4 *__restr
     do {      \
     } while (0)
 #endif
-    for (int r = r_start; r <= rmax;) {
+    // (r_first > r_start: the first shell is wider than the next radius -- the caller applied the rule for the next
+    // radius, below, to what it knows already)
+    for (int r = max(r_start, min(r_first, rmax)); r <= rmax;) {
         DIAG_LANE_ADD(8 * (KC == 1) + 7, 1);  // shells
         DG(dg_sh);
         const int x0 = max(cx - r, 0), x1 = min(cx + r, gx - 1);
@@ -495,7 +505,7 @@ __device__ __forceinline__ int grid_search(const GridView &g, const Pt4 *__restr
         }
         r = min(rn, rmax);  // at r == rmax the box is the whole grid and the loop ends through `all`
     }
-#ifdef PCR_DIAG
+#if defined(PCR_DIAG) && !defined(PCR_DIAG_LIGHT)
     {
         const unsigned long long dt = dg_c + dg_l + dg_r;
         if (atomicMax(&g_diag[24], dt) < dt) {  // the shell search with the most trips so far: what did it do?
@@ -636,6 +646,120 @@ __device__ __forceinline__ bool ring1_pruned(const GridView &g, const Pt4 *__res
         alive = (p < e) | (ri < 9);
     }
     return (wd < settle_b2) | (max_d2 <= settle_b2);
+}
+
+// The shell of radius 2 around the query's cell -- the 5x5x5 cells less the 3x3x3 that ring1_pruned or the filtered walk
+// has been through -- for the queries of a nested index that the first walk leaves open (a quarter of a 16 M LiDAR
+// sweep's samples: 1 cm of noise against 6 mm cells).  grid_search does it one row per trip of its flat loop, each trip
+// behind a dependent pair of cell-table loads: 25 rows, 9 of them opened, 16 candidates -- some 27 dependent trips for a
+// lane, and the wave runs as long as its slowest.  Here a LAYER's (up to eight) x-segments are looked up in straight-line
+// code, all loads in flight together, parked in the lane's column of the row table, and walked as one stream: a layer
+// costs one round trip to the cell table plus its candidates.  Same cells, same ball, chords and pruning rule (a row or
+// a cell is skipped when its slab is provably farther than the K-th best of the moment), same total order: the same
+// exact result.  Returns true when the K-th best is final; false: continue with grid_search from radius 3.
+template <int KC, bool XF, int RS, bool CT>
+__device__ __forceinline__ bool shell2_batched(const GridView &g, const Pt4 *__restrict__ cand, double qx, double qy,
+                                               double qz, double sx, double sy, double sz, double max_d2,
+                                               double bound_scale, double extra_margin, TopK<KC> &top, uint2 *rowtab,
+                                               const Rigid *xf = nullptr) {
+    const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
+    const int cx = cell_coord(sx, g.lo[0], g.inv_h, gx);
+    const int cy = cell_coord(sy, g.lo[1], g.inv_h, gy);
+    const int cz = cell_coord(sz, g.lo[2], g.inv_h, gz);
+    const double margin = g.margin + extra_margin + 9.094947017729282e-13 * (fabs(sx) + fabs(sy) + fabs(sz));
+    const double inv_bs = 1.0 / bound_scale;
+    double wd = top.worst_d();
+    uint32_t wi = top.worst_i();
+    const int x0 = max(cx - 2, 0), x1 = min(cx + 2, gx - 1), y0 = max(cy - 2, 0), y1 = min(cy + 2, gy - 1);
+    const int z0 = max(cz - 2, 0), z1 = min(cz + 2, gz - 1);
+    const int px0 = max(cx - 1, 0), px1 = min(cx + 1, gx - 1);  // the cube walked already
+#pragma unroll 1
+    for (int li = 0; li < 5; ++li) {
+        const int rz = cz + (li == 0 ? 0 : (li & 1 ? -1 : 1) * ((li + 1) >> 1));  // 0, -1, +1, -2, +2: nearest layers first
+        uint32_t cnt = 0;
+        if ((rz >= 0) & (rz < gz)) {
+            const double dz = slab_gap(sz, g.lo[2], rz, g.h, margin);
+            const double rem_z = fmin(wd, max_d2) * inv_bs - dz * dz;
+            if (rem_z >= 0.0) {
+                const bool z_in = (rz >= cz - 1) & (rz <= cz + 1);
+                uint32_t p_[8], e_[8];
+                // slots 0..4: the first (or only) segment of rows cy, cy-1, cy+1, cy-2, cy+2; 5..7: the second segment of
+                // the three rows that cross the cube walked already
+#pragma unroll
+                for (int sl = 0; sl < 8; ++sl) {
+                    const int j = sl < 5 ? sl : sl - 5;
+                    const int ry = cy + (j == 0 ? 0 : (j & 1 ? -1 : 1) * ((j + 1) >> 1));
+                    const bool inner = z_in & (j < 3);
+                    bool ok = (ry >= 0) & (ry < gy) & (sl < 5 || inner);
+                    int xs = sl < 5 ? x0 : px1 + 1, xe = sl < 5 ? (inner ? px0 - 1 : x1) : x1;
+                    const double dy = slab_gap(sy, g.lo[1], ry, g.h, margin);
+                    const double rem = rem_z - dy * dy;
+                    ok &= (rem >= 0.0) & (xs <= xe);
+                    if (rem >= 0.0) {  // the chord the ball cuts out of the row, a cell of slack either side (grid_search's)
+                        const double w = ball_half_width(rem) + margin;
+                        double lo_c = (sx - w - g.lo[0]) * g.inv_h - 1.0, hi_c = (sx + w - g.lo[0]) * g.inv_h + 1.0;
+                        lo_c = fmin(fmax(lo_c, (double)xs), (double)xe + 1.0);
+                        hi_c = fmax(fmin(hi_c, (double)xe), (double)xs - 1.0);
+                        xs = (int)lo_c;
+                        xe = (int)hi_c;
+                    }
+                    ok &= xs <= xe;
+                    const size_t base = ((size_t)(ok ? rz : 0) * gy + (ok ? ry : 0)) * gx;
+                    cell_range<CT>(g, base + (ok ? xs : 0), base + (ok ? xe + 1 : 0), p_[sl], e_[sl]);
+                    if (!ok) e_[sl] = p_[sl];
+                }
+#pragma unroll
+                for (int sl = 0; sl < 8; ++sl)
+                    if (e_[sl] > p_[sl]) {
+                        rowtab[cnt * RS] = make_uint2(p_[sl], e_[sl]);
+                        ++cnt;
+                    }
+            }
+        }
+        uint32_t ri = 0, p = 0, e = 0;
+        bool alive = cnt != 0u;
+        while (alive) {
+            if ((p >= e) & (ri < cnt)) {
+                const uint2 row = rowtab[ri * RS];
+                ++ri;
+                p = row.x;
+                e = row.y;
+                if (e - p > PCR_LONG_RANGE) {  // dense stretch: enter at the query's x instead
+                    windowed_scan<KC, XF>(g.pts, cand, p, e, qx, qy, qz, sx, margin, bound_scale, top, wd, wi, xf);
+                    p = e;
+                }
+            }
+            if (p < e) {
+                Pt4 c[PCR_WALK_UNROLL];
+                const uint32_t last = e - 1;
+#pragma unroll
+                for (int u = 0; u < PCR_WALK_UNROLL; ++u) c[u] = cand[min(p + (uint32_t)u, last)];
+                const uint32_t left = e - p;
+                p += min(left, (uint32_t)PCR_WALK_UNROLL);
+#pragma unroll
+                for (int u = 0; u < PCR_WALK_UNROLL; ++u) {
+                    const double d = cand_d2<XF>(xf, qx, qy, qz, c[u]);
+                    const uint32_t ci = (uint32_t)c[u].w;
+                    if (((uint32_t)u < left) & better(d, ci, wd, wi)) {
+                        top.insert(d, ci);
+                        wd = top.worst_d();
+                        wi = top.worst_i();
+                    }
+                }
+            }
+            alive = (p < e) | (ri < cnt);
+        }
+    }
+    // ---- can anything outside the 5x5x5 cells still matter? (grid_search's rule)
+    if ((x0 == 0) & (x1 == gx - 1) & (y0 == 0) & (y1 == gy - 1) & (z0 == 0) & (z1 == gz - 1)) return true;
+    double ox = fmax(fmax(g.lo[0] - sx, sx - g.hi[0]), 0.0) - margin;
+    double oy = fmax(fmax(g.lo[1] - sy, sy - g.hi[1]), 0.0) - margin;
+    double oz = fmax(fmax(g.lo[2] - sz, sz - g.hi[2]), 0.0) - margin;
+    ox = ox > 0.0 ? ox : 0.0;
+    oy = oy > 0.0 ? oy : 0.0;
+    oz = oz > 0.0 ? oz : 0.0;
+    const double b2 = box_bound2(g, sx, sy, sz, margin, ox * ox, oy * oy, oz * oz, x0, x1, y0, y1, z0, z1) * bound_scale;
+    return (wd < b2) | (max_d2 <= b2);
 }
 
 // The per-lane search the kernels use: pruned ring 1, then (rarely) the generic shells from ring 2 on.
