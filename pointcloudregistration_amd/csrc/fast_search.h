@@ -620,7 +620,7 @@ __device__ __forceinline__ void multi_lane_search(const MultiView &M, const Mult
     const int L = M.levels;
     const double qmargin = extra_margin + 9.094947017729282e-13 * (fabs(sx) + fabs(sy) + fabs(sz));
     uint32_t holds = 0, open = 0;
-    const unsigned long long diag_p0 = DIAG_T();  // (diagnostic build: the wave's time in each of the three passes, slots 42..47)
+    [[maybe_unused]] const unsigned long long diag_p0 = DIAG_T();  // (diagnostic build: the wave's time in each of the three passes, slots 42..47)
     if (active)
         for (int it = 0; it < 2 * L; ++it) {
             const int l = it < L ? L - 1 - it : it - L;
@@ -692,7 +692,7 @@ __device__ __forceinline__ void multi_lane_search(const MultiView &M, const Mult
         }
     DIAG_ADD(42 + 3 * XF, DIAG_T() - diag_p0);
     if (__any(open != 0)) {
-        const unsigned long long diag_p1 = DIAG_T();
+        [[maybe_unused]] const unsigned long long diag_p1 = DIAG_T();
         uint32_t left = 0;
         for (int it = 0; it < 2 * L; ++it) {
             const int l = it < L ? L - 1 - it : it - L;
@@ -723,7 +723,7 @@ __device__ __forceinline__ void multi_lane_search(const MultiView &M, const Mult
             }
         }
         DIAG_ADD(43 + 3 * XF, DIAG_T() - diag_p1);
-        const unsigned long long diag_p2 = DIAG_T();
+        [[maybe_unused]] const unsigned long long diag_p2 = DIAG_T();
         // ---- pass 3: one unfinished query at a time, by the whole wave ----
         unsigned long long pending = COOP ? __ballot(left != 0) : 0ull;
         while (pending) {

@@ -654,9 +654,8 @@ __device__ __forceinline__ bool ring1_pruned(const GridView &g, const Pt4 *__res
 // behind a dependent pair of cell-table loads: 25 rows, 9 of them opened, 16 candidates -- some 27 dependent trips for a
 // lane, and the wave runs as long as its slowest.  Here a LAYER's (up to eight) x-segments are looked up in straight-line
 // code, all loads in flight together, parked in the lane's column of the row table, and walked as one stream: a layer
-// costs one round trip to the cell table plus its candidates.  Same cells, same ball, chords and pruning rule (a row or
-// a cell is skipped when its slab is provably farther than the K-th best of the moment), same total order: the same
-// exact result.  Returns true when the K-th best is final; false: continue with grid_search from radius 3.
+// costs one round trip to the cell table plus its candidates.  Same cells, same pruning rule (a layer or a row is skipped
+// when its slab is provably farther than the K-th best of the moment), same total order: the same exact result.  Returns true when the K-th best is final; false: continue with grid_search from radius 3.
 template <int KC, bool XF, int RS, bool CT>
 __device__ __forceinline__ bool shell2_batched(const GridView &g, const Pt4 *__restrict__ cand, double qx, double qy,
                                                double qz, double sx, double sy, double sz, double max_d2,
@@ -673,6 +672,12 @@ __device__ __forceinline__ bool shell2_batched(const GridView &g, const Pt4 *__r
     const int x0 = max(cx - 2, 0), x1 = min(cx + 2, gx - 1), y0 = max(cy - 2, 0), y1 = min(cy + 2, gy - 1);
     const int z0 = max(cz - 2, 0), z1 = min(cz + 2, gz - 1);
     const int px0 = max(cx - 1, 0), px1 = min(cx + 1, gx - 1);  // the cube walked already
+    double dy2_[5];  // the rows' slab distances, squared: the same in every layer
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const double dy = slab_gap(sy, g.lo[1], cy + (j == 0 ? 0 : (j & 1 ? -1 : 1) * ((j + 1) >> 1)), g.h, margin);
+        dy2_[j] = dy * dy;
+    }
 #pragma unroll 1
     for (int li = 0; li < 5; ++li) {
         const int rz = cz + (li == 0 ? 0 : (li & 1 ? -1 : 1) * ((li + 1) >> 1));  // 0, -1, +1, -2, +2: nearest layers first
@@ -692,17 +697,10 @@ __device__ __forceinline__ bool shell2_batched(const GridView &g, const Pt4 *__r
                     const bool inner = z_in & (j < 3);
                     bool ok = (ry >= 0) & (ry < gy) & (sl < 5 || inner);
                     int xs = sl < 5 ? x0 : px1 + 1, xe = sl < 5 ? (inner ? px0 - 1 : x1) : x1;
-                    const double dy = slab_gap(sy, g.lo[1], ry, g.h, margin);
-                    const double rem = rem_z - dy * dy;
+                    const double rem = rem_z - dy2_[j];
                     ok &= (rem >= 0.0) & (xs <= xe);
-                    if (rem >= 0.0) {  // the chord the ball cuts out of the row, a cell of slack either side (grid_search's)
-                        const double w = ball_half_width(rem) + margin;
-                        double lo_c = (sx - w - g.lo[0]) * g.inv_h - 1.0, hi_c = (sx + w - g.lo[0]) * g.inv_h + 1.0;
-                        lo_c = fmin(fmax(lo_c, (double)xs), (double)xe + 1.0);
-                        hi_c = fmax(fmin(hi_c, (double)xe), (double)xs - 1.0);
-                        xs = (int)lo_c;
-                        xe = (int)hi_c;
-                    }
+                    // (no chord here: trimming a row of at most five cells to what the ball cuts out of it costs more fp64
+                    // arithmetic than the few candidates it spares -- 16 M LiDAR iteration 11.74 with, 11.61 ms without)
                     ok &= xs <= xe;
                     const size_t base = ((size_t)(ok ? rz : 0) * gy + (ok ? ry : 0)) * gx;
                     cell_range<CT>(g, base + (ok ? xs : 0), base + (ok ? xe + 1 : 0), p_[sl], e_[sl]);
