@@ -705,20 +705,8 @@ __device__ __forceinline__ void multi_lane_search(const MultiView &M, const Mult
             }
             if (go) {
                 // the 5x5x5 cells first, a layer's rows looked up together; what that leaves open goes on shell by shell
-                int r_done = 0;
-                if (!shell2_batched<KC, XF, PCR_ROW_STRIDE, CT>(g, cand_all + (g.pts - M.all), qx, qy, qz, sx, sy, sz, max_d2, bound_scale,
-                                                                extra_margin, top, rowtab, xf)) {
-                    // the next radius by grid_search's rule: double, but never past what the ball of everything that can
-                    // still matter needs
-                    int r_first = 4;
-                    const double reach2 = fmin(top.worst_d(), max_d2);
-                    if (reach2 < PCR_INF) {
-                        const double cells_needed = (sqrt(reach2 / bound_scale) + g.margin + qmargin) * g.inv_h + 2.0;
-                        r_first = cells_needed < 4.0 ? max((int)cells_needed, 3) : 4;
-                    }
-                    r_done = grid_search<KC, true, XF, COOP ? PCR_LANE_RMAX : 0, CT>(
-                        g, cand_all + (g.pts - M.all), qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, 3, xf, r_first);
-                }
+                const int r_done = shells_beyond_ring1<KC, true, XF, COOP ? PCR_LANE_RMAX : 0, PCR_ROW_STRIDE, CT>(
+                    g, cand_all + (g.pts - M.all), qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, rowtab, xf);
                 left |= (uint32_t)r_done << (4 * l);  // (PCR_LANE_RMAX <= 15, at most 6 levels)
             }
         }

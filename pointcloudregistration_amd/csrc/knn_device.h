@@ -760,16 +760,43 @@ __device__ __forceinline__ bool shell2_batched(const GridView &g, const Pt4 *__r
     return (wd < b2) | (max_d2 <= b2);
 }
 
-// The per-lane search the kernels use: pruned ring 1, then (rarely) the generic shells from ring 2 on.
-template <int KC, bool XF = false, int RS = PCR_ROW_STRIDE>
+// Everything beyond the 3x3x3 cells: the 5x5x5 cells a layer at a time, then -- for what that leaves open -- the shell
+// search, its first shell at the radius grid_search's own rule for the next radius gives with what is known by now
+// (double, but never past what the ball of everything that can still matter needs).  Returns what grid_search returns.
+template <int KC, bool WINDOW, bool XF, int LANE_RMAX, int RS, bool CT>
+__device__ __forceinline__ int shells_beyond_ring1(const GridView &g, const Pt4 *__restrict__ cand, double qx, double qy,
+                                                   double qz, double sx, double sy, double sz, double max_d2,
+                                                   double bound_scale, double extra_margin, TopK<KC> &top, uint2 *rowtab,
+                                                   const Rigid *xf = nullptr) {
+    if (shell2_batched<KC, XF, RS, CT>(g, cand, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, rowtab, xf)) return 0;
+    int r_first = 4;
+    const double reach2 = fmin(top.worst_d(), max_d2);
+    if (reach2 < PCR_INF) {
+        const double margin = g.margin + extra_margin + 9.094947017729282e-13 * (fabs(sx) + fabs(sy) + fabs(sz));
+        const double cells_needed = (sqrt(reach2 / bound_scale) + margin) * g.inv_h + 2.0;
+        r_first = cells_needed < 4.0 ? max((int)cells_needed, 3) : 4;
+    }
+    return grid_search<KC, WINDOW, XF, LANE_RMAX, CT>(g, cand, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, 3, xf,
+                                                      r_first);
+}
+
+// The per-lane search the kernels use: pruned ring 1, then (rarely) the shells beyond it.
+// BATCH2 = false: the shells are grid_search's from radius 2 on (the filtered step kernel's reverse fall-back: with the
+// layer-at-a-time scan compiled in as well, that kernel spills 78 registers instead of 56 and its 1 M iteration takes
+// 122.8 us instead of 120.2)
+template <int KC, bool XF = false, int RS = PCR_ROW_STRIDE, bool BATCH2 = true>
 __device__ __forceinline__ void lane_search(const GridView &g, const Pt4 *__restrict__ cand, double qx, double qy,
                                             double qz, double sx, double sy, double sz, double max_d2,
                                             double bound_scale, double extra_margin, TopK<KC> &top,
                                             uint2 *rowtab, const Rigid *xf = nullptr) {
     DIAG_LANE_ADD(8 * (KC == 1) + 5, 1);  // lane searches
     const bool fin1 = ring1_pruned<KC, XF, RS>(g, cand, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, rowtab, xf);
-    if (!fin1)
-        grid_search<KC, false, XF>(g, cand, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, 2, xf);
+    if (!fin1) {
+        if constexpr (BATCH2)
+            shells_beyond_ring1<KC, false, XF, 0, RS, false>(g, cand, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, rowtab, xf);
+        else
+            grid_search<KC, false, XF>(g, cand, qx, qy, qz, sx, sy, sz, max_d2, bound_scale, extra_margin, top, 2, xf);
+    }
 }
 
 // squared distance from the grid-frame query to a level's box of points, shrunk by the margin (0 inside)

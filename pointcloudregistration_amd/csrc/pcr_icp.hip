@@ -601,9 +601,13 @@ __device__ PCR_FALLBACK_INLINE void fallback_forward(const StepArgs *__restrict_
         shells = !ring1_pruned<KC, false, 64>(G, Ap->tgt.all, px, py, pz, px, py, pz, fmax_d2, fwd_scale, 0.0, top, my_rows,
                                           (const Rigid *)nullptr);
     }
-    if (shells) grid_search<KC, false, false>(G, Ap->tgt.all, px, py, pz, px, py, pz, fmax_d2, fwd_scale, 0.0, top, 2);
+    if (shells)
+        shells_beyond_ring1<KC, false, false, 0, 64, false>(G, Ap->tgt.all, px, py, pz, px, py, pz, fmax_d2, fwd_scale, 0.0, top, my_rows);
     top.slot(k, *dF, *j);
 }
+// BATCH2: lane_search's (the batch kernel, whose small problems' latency is the fall-back lanes': 3 250 -> 3 420 fits/s
+// on C4 with it; the single-problem kernel without: 120.2 us per 1 M iteration against 122.8)
+template <bool BATCH2>
 __device__ PCR_FALLBACK_INLINE uint32_t fallback_reverse(const StepArgs *__restrict__ Ap, double qx, double qy, double qz, double sx,
                                                          double sy, double sz, double rbs, double rem_, double dF, uint32_t orig,
                                                          uint2 *my_rows) {
@@ -612,7 +616,7 @@ __device__ PCR_FALLBACK_INLINE uint32_t fallback_reverse(const StepArgs *__restr
     rt.idx[0] = orig;
     const GridView G = Ap->src.v[0];
     const Rigid M = Ap->dyn->M;
-    lane_search<1, true, 64>(G, Ap->src.all, qx, qy, qz, sx, sy, sz, PCR_INF, rbs, rem_, rt, my_rows, &M);
+    lane_search<1, true, 64, BATCH2>(G, Ap->src.all, qx, qy, qz, sx, sy, sz, PCR_INF, rbs, rem_, rt, my_rows, &M);
     return rt.idx[0];
 }
 
@@ -633,7 +637,7 @@ constexpr int FAST_RS = 64;  // the filtered kernel's blocks are single waves: 6
 
 // One tile -- 64 samples, one lane each -- of one problem.  smem: the wave's WAVE_LDS_BYTES (row table, then the
 // reduction's scratch).
-template <int KC>
+template <int KC, bool BATCHED = false>  // BATCHED: called by the kernel of many small problems (see fallback_reverse)
 __device__ __forceinline__ void fast_tile(const StepArgs *__restrict__ Ap, uint32_t tile, uint32_t ntiles,
                                           unsigned char *smem) {
 #ifdef PCR_BLOCK_TIMES
@@ -766,7 +770,7 @@ __device__ __forceinline__ void fast_tile(const StepArgs *__restrict__ Ap, uint3
         const bool s_known = rev_active & rev_done;
         DIAG_ADD(34, __any(!rev_done) ? 1 : 0);   // ... some lane's reverse search
         if (__any(!rev_done)) {
-            if (!rev_done) rv = fallback_reverse(Ap, qx, qy, qz, sx, sy, sz, rbs, rem_, dF, orig, my_rows);
+            if (!rev_done) rv = fallback_reverse<BATCHED>(Ap, qx, qy, qz, sx, sy, sz, rbs, rem_, dF, orig, my_rows);
         }
         if (need_rev) {
             r = rv;
@@ -842,7 +846,7 @@ __global__ void __launch_bounds__(64, KC > 4 ? PCR_FAST_WAVES8 : PCR_FAST_WAVES)
     }
     const StepArgs *Ap = argv[lo];
     if (reload_from(reload_from(Ap)->dyn)->done) return;  // uniform over the problem's blocks
-    fast_tile<KC>(Ap, b - first[lo], first[lo + 1] - first[lo], smem);
+    fast_tile<KC, true>(Ap, b - first[lo], first[lo + 1] - first[lo], smem);
 }
 
 // Small clouds: both searches as tiled brute force (LDS-staged tiles, broadcast reads).
