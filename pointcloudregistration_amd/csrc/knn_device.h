@@ -672,6 +672,7 @@ __device__ __forceinline__ bool shell2_batched(const GridView &g, const Pt4 *__r
     const int x0 = max(cx - 2, 0), x1 = min(cx + 2, gx - 1), y0 = max(cy - 2, 0), y1 = min(cy + 2, gy - 1);
     const int z0 = max(cz - 2, 0), z1 = min(cz + 2, gz - 1);
     const int px0 = max(cx - 1, 0), px1 = min(cx + 1, gx - 1);  // the cube walked already
+    DIAG_LANE_ADD(35, 1);  // layer-at-a-time scans of the 5x5x5 cells
     double dy2_[5];  // the rows' slab distances, squared: the same in every layer
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
