@@ -186,7 +186,7 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
                                            double seed_d, uint32_t seed_i, double &out_d, uint32_t &out_i,
                                            uint2 *rowtab, const RG *xf, FastExact<KC> *all = nullptr,
                                            StageClock *clk = nullptr, Pt4 *win = nullptr, uint32_t *win_pos = nullptr,
-                                           bool active = true) {
+                                           bool active = true, uint32_t *diag_trips = nullptr) {
     constexpr int KP = KC + 2;
     const uint32_t *__restrict__ cs = g.cs;
     const uint2 *__restrict__ shadow = g.shadow;
@@ -355,6 +355,9 @@ __device__ __forceinline__ bool fast_ring1(const GV &g, const Pt4 *__restrict__ 
     while (alive) {
         DIAG_ADD(24 + XF, 1);  // wave trips
         DIAG_LANE_ADD(36 + XF, 1);                                   // ... lane trips (the wave's are the slowest lane's)
+#ifdef PCR_DIAG
+        if (diag_trips) ++*diag_trips;
+#endif
         DIAG_LANE_ADD(38 + XF, (e == p) ? 1 : 0);                    // ... of which with nothing left of the current row
         const uint32_t rem = e - p;
         uint32_t p2 = 0, e2 = 0, pb2 = 0;

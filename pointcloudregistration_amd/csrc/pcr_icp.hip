@@ -637,6 +637,9 @@ constexpr int FAST_RS = 64;  // the filtered kernel's blocks are single waves: 6
 
 // One tile -- 64 samples, one lane each -- of one problem.  smem: the wave's WAVE_LDS_BYTES (row table, then the
 // reduction's scratch).
+#ifdef PCR_DIAG
+static __device__ uint8_t g_trips[2][1 << 20];  // (diagnostic build) per sample slot of the last launch: phase-2 trips
+#endif
 template <int KC, bool BATCHED = false>  // BATCHED: called by the kernel of many small problems (see fallback_reverse)
 __device__ __forceinline__ void fast_tile(const StepArgs *__restrict__ Ap, uint32_t tile, uint32_t ntiles,
                                           unsigned char *smem) {
@@ -656,6 +659,9 @@ __device__ __forceinline__ void fast_tile(const StepArgs *__restrict__ Ap, uint3
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t t = tile * 64u + lane;
     uint2 *my_rows = (uint2 *)smem + lane;
+#ifdef PCR_DIAG
+    uint32_t diag_trips_f = 0, diag_trips_r = 0;  // this sample's phase-2 trips (forward, reverse): g_trips, read by pcr_diag_read_trips
+#endif
     uint32_t pos = 0, orig = 0, slot = 0;
     double px = 0, py = 0, pz = 0;
     float dk_prev = __builtin_huge_valf();  // last iteration's K-th squared distance (loaded beside the point: one wait)
@@ -706,7 +712,11 @@ __device__ __forceinline__ void fast_tile(const StepArgs *__restrict__ Ap, uint3
         // phases 1-2 and help their partners in phase 3: fast_search.h, PAIR)
         fwd_done = fast_ring1<KC, false, false, PCR_FAST_TRIES_FWD, PCR_FAST_U_FWD, FAST_RS, PCR_FAST_PAIR != 0>(
             GT, GT.pts, px, py, pz, px, py, pz, fmax_d2, bound_d2, fwd_scale, 0.0, GT.key_delta, A->k, 0.0, 0u, dF, j, my_rows,
-            (const Rigid *)nullptr, &fx, pf, nullptr, &qpos, fin);
+            (const Rigid *)nullptr, &fx, pf, nullptr, &qpos, fin
+#ifdef PCR_DIAG
+            , &diag_trips_f
+#endif
+            );
         if (!fin) {
             fwd_done = true;
             dF = fmax_d2;
@@ -760,7 +770,11 @@ __device__ __forceinline__ void fast_tile(const StepArgs *__restrict__ Ap, uint3
             Pt4 srec_;
             const bool done_ = fast_ring1<1, true, true, 1, PCR_FAST_U_REV, FAST_RS, PCR_FAST_PAIR != 0>(
                 GS, GS.pts, qx, qy, qz, sx, sy, sz, PCR_INF, dF, rbs, rem_, rev_delta, 1, dF, orig, dRv_, rv_, my_rows, &D->M,
-                nullptr, pr, &srec_, nullptr, rev_active);
+                nullptr, pr, &srec_, nullptr, rev_active
+#ifdef PCR_DIAG
+                , &diag_trips_r
+#endif
+                );
             if (rev_active) {
                 rev_done = done_;
                 rv = rv_;
@@ -781,6 +795,12 @@ __device__ __forceinline__ void fast_tile(const StepArgs *__restrict__ Ap, uint3
             keep = passF && dR < A->thr_rev;  // strict < (:98)
         }
     }
+#ifdef PCR_DIAG
+    if (t < (1u << 20)) {
+        g_trips[0][t] = (uint8_t)min(diag_trips_f, 255u);
+        g_trips[1][t] = (uint8_t)min(diag_trips_r, 255u);
+    }
+#endif
     FAST_STAMP(2);
 #ifdef PCR_BLOCK_TIMES
     ck[2] = (uint32_t)__builtin_readcyclecounter();
@@ -1952,6 +1972,9 @@ extern "C" int pcr_diag_block_times(unsigned long long *out, unsigned n) {
 }
 #endif
 #ifdef PCR_DIAG
+extern "C" int pcr_diag_read_trips(unsigned char *out /* [2][1 << 20] */) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pcr::g_trips), 2u << 20) == hipSuccess ? 0 : -2;
+}
 extern "C" int pcr_diag_read_icp(unsigned long long out[48], int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcr::g_diag), sizeof(unsigned long long) * 48) != hipSuccess) return -2;
     if (reset) {
