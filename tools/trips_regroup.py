@@ -3,8 +3,8 @@
 Needs the diagnostic build (make -C pointcloudregistration_amd/csrc diag; PCR_LIB=.../libpcr_diag.so), which records
 every sample's forward and reverse trips of the last launch (pcr_diag_read_trips).  Prints, for iterations 5, 6 and 12 of
 the 1 M x 1 M fit: the mean over waves of the slowest lane's trips as the kernel runs now, with the samples of 4 / 16 / 64
-neighbouring tiles sorted by their CURRENT counts (the ideal), and sorted by the counts of an EARLIER iteration (what a
-kernel could know).
+neighbouring tiles sorted by their CURRENT counts (the ideal), sorted by the counts of an EARLIER iteration (what a
+kernel could know), and with 2 / 4 / 8 neighbouring lanes sharing their rows evenly.
 """
 import sys, ctypes as C, numpy as np
 import os
@@ -37,6 +37,14 @@ for it in range(1, 13):
                 grp = np.sort(x[:ng].reshape(-1, 64 * g), axis=1).reshape(-1, 64)
                 line += f"; sorted within {g} tiles: {grp.max(1).mean():.2f}"
             print(line, flush=True)
+        # lanes SHARING their work: 2 / 4 / 8 neighbouring lanes split the sum of their trips evenly (rounded up)
+        n64 = (N // 64) * 64
+        for share in (2, 4, 8):
+            f = tr[0][:n64].reshape(-1, 64 // share, share).sum(2)
+            r = tr[1][:n64].reshape(-1, 64 // share, share).sum(2)
+            fm = -(-f // share); rm = -(-r // share)
+            print(f"   it {it}: {share} lanes sharing their rows: max(fwd)+max(rev) per wave {(fm.max(1) + rm.max(1)).mean():.2f} "
+                  f"(now {(tr[0][:n64].reshape(-1, 64).max(1) + tr[1][:n64].reshape(-1, 64).max(1)).mean():.2f})", flush=True)
         if prev is not None:
             # how well does last look's count predict this one's?  regroup by the PREVIOUS counts, evaluate with the current
             for g in (4, 16):
