@@ -21,6 +21,10 @@ extern "C" {
 void pcrh_reset(void);
 void pcrh_set_device(int device);
 void pcrh_set_verbose(int on);
+/* pcr_index_params.compact_tables (include/pcr.h) for every index the plugin layer builds from now on: 0 (default)
+ * dense cell tables, 1 compact tables for the sparse levels of nested grids, 2 for every level of a nested grid.
+ * No counterpart in the reference (its KD-tree has no such choice); results do not depend on it. */
+void pcrh_set_compact_tables(uint32_t mode);
 
 /* sample sharding over ranks: this process runs samples [begin,begin+count) of every step and
  * `fn` sums the 17 partials over the ranks in place (return 0 on success). world <= 1 disables it. */

@@ -1,5 +1,7 @@
 #include "device_session.h"
 
+#include <cstring>
+
 using namespace pcrhost;
 
 CDeviceSession *CDeviceSession::getInstance() {
@@ -40,7 +42,10 @@ const SDeviceCloud *CDeviceSession::__acquire(const void *vKey, const double *vP
     }
     SDeviceCloud Entry;
     int Status = pcr_cloud_upload(pContext, vPos, vNumPoints, &Entry.pCloud);
-    if (Status == PCR_OK) Status = pcr_index_build(pContext, Entry.pCloud, NULL, &Entry.pIndex);
+    pcr_index_params Params;
+    memset(&Params, 0, sizeof Params);  // all defaults ...
+    Params.compact_tables = m_CompactTables;  // ... but what the host asked for here
+    if (Status == PCR_OK) Status = pcr_index_build(pContext, Entry.pCloud, &Params, &Entry.pIndex);
     if (Status != PCR_OK) {
         m_LastError = std::string(pcr_strerror(Status)) + " -- " + pcr_last_error();
         if (Entry.pCloud) pcr_cloud_free(Entry.pCloud);

@@ -35,6 +35,8 @@ public:
     void release(const void *vKey);
     void releaseAll();
     void setDevice(int vDevice) { m_Device = vDevice; }
+    // pcr_index_params.compact_tables of every index built from now on (0: the library's default, dense cell tables)
+    void setCompactTables(unsigned int vMode) { m_CompactTables = vMode; }
     const std::string &lastError() const { return m_LastError; }
     // sample sharding for the multi-GPU loop: this process handles samples
     // [begin, begin+count) of every sample set; a hook sums the 17 partials over the ranks.
@@ -50,11 +52,12 @@ public:
     int allReduce(double *vioPartials17) const { return (m_World > 1 && m_AllReduce) ? m_AllReduce(vioPartials17, m_AllReduceUser) : 0; }
 
 private:
-    CDeviceSession() : m_pContext(NULL), m_Device(0), m_ContextTried(false), m_Rank(0), m_World(1), m_AllReduce(NULL), m_AllReduceUser(NULL) {}
+    CDeviceSession() : m_pContext(NULL), m_Device(0), m_CompactTables(0), m_ContextTried(false), m_Rank(0), m_World(1), m_AllReduce(NULL), m_AllReduceUser(NULL) {}
     const SDeviceCloud *__acquire(const void *vKey, const double *vPos, unsigned int vNumPoints);
 
     pcr_ctx *m_pContext;
     int m_Device;
+    unsigned int m_CompactTables;
     bool m_ContextTried;
     std::map<const void *, SDeviceCloud> m_Clouds;
     std::string m_LastError;

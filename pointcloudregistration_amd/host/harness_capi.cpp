@@ -59,6 +59,7 @@ void pcrh_reset(void) {
 }
 
 void pcrh_set_device(int device) { pcrhost::CDeviceSession::getInstance()->setDevice(device); }
+void pcrh_set_compact_tables(uint32_t mode) { pcrhost::CDeviceSession::getInstance()->setCompactTables(mode); }
 
 void pcrh_set_verbose(int on) { hiveEventLogger::quiet() = !on; }
 

@@ -17,6 +17,7 @@ SYMBOLS = {
     "pcrh_reset": (None, []),
     "pcrh_set_device": (None, [C.c_int]),
     "pcrh_set_verbose": (None, [C.c_int]),
+    "pcrh_set_compact_tables": (None, [C.c_uint32]),
     "pcrh_set_sharding": (None, [C.c_uint32, C.c_uint32, ALLREDUCE_FN, C.c_void_p]),
     "pcrh_config_parse_file": (C.c_int, [C.c_char_p]),
     "pcrh_config_parse_text": (None, [C.c_char_p]),
@@ -71,6 +72,11 @@ def _s(x):
 
 def reset():
     lib().pcrh_reset()
+
+
+def set_compact_tables(mode):
+    """pcr_index_params.compact_tables for every index the plugin layer builds from now on (0: dense, the default)."""
+    lib().pcrh_set_compact_tables(int(mode))
 
 
 def config_text(text):

@@ -170,3 +170,26 @@ def test_fused_loop_equals_stage_by_stage(host, name):
         assert (a["traj"] == b["traj"]).all() and (a["R"] == b["R"]).all() and (a["T"] == b["T"]).all()
         if samples is None:
             assert a["iterations"] == int(g["iterations"])
+
+
+def test_plugin_layer_fit_with_compact_cell_tables(host):
+    """pcrh_set_compact_tables: a LiDAR-like pair (nested grids) fitted through the plugin layer with compact cell tables
+    for every level == the same fit with dense tables, bit for bit (iterations, message, every row of the trajectory)."""
+    from pointcloudregistration_amd import synth
+    src, tgt, Rm, t = synth.lidar_pair(120_000, 31)
+    R0, T0 = synth.colmajor(synth.euler_zyx(0.02, -0.01, 0.03) @ Rm), t + np.array([0.05, -0.03, 0.01])
+    host.config_text(REGCFG + "BaseConvergenceCriteria.MI = 8\nCorrespondenceEstimationClosestPoints.NN = 4\n")
+    out = {}
+    try:
+        for mode in (0, 2):
+            host.set_compact_tables(mode)
+            out[mode] = host.fit(src, tgt, R0=R0, T0=T0)
+            host.reset()
+            host.config_text(REGCFG + "BaseConvergenceCriteria.MI = 8\nCorrespondenceEstimationClosestPoints.NN = 4\n")
+    finally:
+        host.set_compact_tables(0)
+    a, b = out[0], out[2]
+    assert a["status"] == 0 and b["status"] == 0 and a["iterations"] >= 2
+    assert a["iterations"] == b["iterations"] and a["msg"] == b["msg"]
+    assert (a["traj"] == b["traj"]).all() and (a["R"] == b["R"]).all() and (a["T"] == b["T"]).all()
+    assert a["traj"][0, 13] > 1000   # the fits do pair points
