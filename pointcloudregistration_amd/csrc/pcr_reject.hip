@@ -157,6 +157,9 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 // on the kept pairs of a converged 1 M x 1 M fit, per search: 2.4 shells, 7.8 row groups, 5.9 chunks, 259 candidates,
 // 48 insertions -- the source side asks for the neighbours of a TRANSFORMED point in the UNtransformed cloud (:52,:75),
 // 4.5 cells off the surface at that fit's translation, so its searches reach 5-6 cells out)
+#ifndef PCR_REJ_MERGE_MIN
+#define PCR_REJ_MERGE_MIN 12  // candidates of a group that beat the k-th best: from this many on the group is sorted and merged
+#endif
 #ifdef PCR_REJ_DIAG
 __device__ unsigned long long g_rej_diag[8];
 #define RDIAG(i, v) do { if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_rej_diag[i], (unsigned long long)(v)); } while (0)
@@ -291,15 +294,33 @@ __device__ __forceinline__ double wave_sq_dist_to_centroid(const GridView &g, co
                         ci = (uint32_t)c.w;
                     }
                     // ---- the first 64 candidates (for most points: everything the 3x3x3 cells hold) are SORTED across the
-                    // lanes -- a bitonic network, 21 compare-exchange steps -- and the first k of them are the list
-                    if (empty) {
-                        empty = false;
+                    // lanes -- a bitonic network, 21 compare-exchange steps -- and the first k of them are the list.  A later
+                    // group of 64 in which MANY beat the k-th best so far (the group after the first, typically: the k-th of
+                    // 64 is still loose) goes the same way instead of entering one at a time: sorted (what cannot enter as
+                    // +inf), reversed, and merged with the list -- min(list[i], sorted[63 - i]) holds the 64 smallest of both as a
+                    // bitonic sequence, six more steps sort it.  Same total order (d2, index): the same list.
+                    bool pend = have & better(d, ci, tau_d, tau_i);
+                    if (empty || __popcll(__ballot(pend)) >= PCR_REJ_MERGE_MIN) {
+                        if (!pend) {
+                            d = PCR_INF;
+                            ci = PCR_NO_INDEX;
+                        }
                         bitonic_stage<2, 1>(d, ci, lane);
                         bitonic_stage<4, 2>(d, ci, lane);
                         bitonic_stage<8, 4>(d, ci, lane);
                         bitonic_stage<16, 8>(d, ci, lane);
                         bitonic_stage<32, 16>(d, ci, lane);
                         bitonic_stage<64, 32>(d, ci, lane);
+                        if (!empty) {
+                            const double rd = xor_lane<31>(xor_lane<32>(d));
+                            const uint32_t ri = xor_lane<31>(xor_lane<32>(ci));
+                            const bool take = better(rd, ri, Ld, Li);  // (lanes from k on hold +inf: they take the group's)
+                            d = take ? rd : Ld;
+                            ci = take ? ri : Li;
+                            bitonic_stage<64, 32>(d, ci, lane);
+                            RDIAG(6, 1);  // merged groups
+                        }
+                        empty = false;
                         Ld = lane < k ? d : PCR_INF;
                         Li = lane < k ? ci : PCR_NO_INDEX;
                         tau_d = wave_bcast(Ld, k - 1);
@@ -307,7 +328,6 @@ __device__ __forceinline__ double wave_sq_dist_to_centroid(const GridView &g, co
                         continue;
                     }
                     // ---- later ones that beat the k-th best enter the list, one at a time
-                    bool pend = have & better(d, ci, tau_d, tau_i);
                     for (;;) {
                         const unsigned long long m = __ballot(pend);
                         if (!m) break;
