@@ -68,6 +68,36 @@ def test_sample_subset_and_order(pcr, ctx, oracle):
     assert out["partials"][0] == want["P"]
 
 
+@pytest.mark.parametrize("k", [5, 6, 8])
+def test_k5_to_8_step_and_fit_vs_oracle(pcr, ctx, oracle, k):
+    """K = 5 ... 8 run the filtered kernel's 8-entry instance: one ICRP iteration against the oracle sample by sample
+    (forward K-th neighbour, reverse winner, flag, pair count), and a whole device-resident fit with the reference's
+    criteria against the oracle's restatement of CIterativeFit::fit (iterations, state, pairs per iteration exactly,
+    trajectory to 1e-9)."""
+    from pointcloudregistration_amd import synth
+    src, tgt, Rm, t = synth.registration_pair(60000, 60000, 100 + k)
+    six, tix = pcr.Index(ctx, pcr.Cloud(ctx, src), kind=pcr.INDEX_GRID), pcr.Index(ctx, pcr.Cloud(ctx, tgt), kind=pcr.INDEX_GRID)
+    U = tix.unique_sq_dist()
+    assert U == oracle.uniq_sq_dist(tgt)
+    R0, T0 = synth.coarse_initial_transform(Rm, t, 60000)
+    want = oracle.icrp_correspondences(src, tgt, oracle.KdOld(tgt, k), R0, T0, k, U * 36.0, U * 4.0, threads=16)
+    got = pcr.icp_step(ctx, six, tix, R0, T0, k, U * 36.0, U * 4.0, exact=True)
+    assert pcr.last_step_kernel() == "icp_step_fast_kernel<8>"
+    assert (got["fwd"] == want["fwd"]).all() and (got["rev"] == want["rev"]).all() and (got["keep"] == want["keep"]).all()
+    assert got["partials"][0] == want["P"] > 1000
+    conv = pcr.ConvergenceParams.regcfg(12)
+    fit = pcr.Fit(ctx, six, tix, k, U * 36.0, U * 4.0, conv=conv, unique_sq_dist=U, traj_cap=16).run(R0, T0, 12)
+    ref = oracle.fit(src, tgt, k=k, sdft=36.0, ndft=4.0, conv=oracle.ConvParams.regcfg(12), R0=R0, T0=T0, threads=16)
+    assert fit["iterations"] == ref["iterations"] and fit["state"] == ref["state"]
+    rt = np.asarray(ref["traj"])
+    assert (fit["traj"][:, 13] == rt[:, 13]).all()
+    np.testing.assert_allclose(fit["traj"][:, :12], rt[:, :12], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(fit["R"], ref["R"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(fit["T"], ref["T"], rtol=0, atol=1e-9)
+    six.close()
+    tix.close()
+
+
 def test_no_pair_survives(pcr, ctx):
     """Far-apart clouds: the reference divides by zero (RegUtilityFunctions.cpp:71); the ABI reports it."""
     g, src, tgt, six, tix = _indices(pcr, ctx, "patch_k1", "grid")
